@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Record outputs of the real reference as golden vectors (build container only).
+
+Run:  MPLBACKEND=Agg python tests/golden/gen_golden.py [/root/reference]
+
+Imports the reference's ``utils.circle_fitting``, ``utils.boundary`` and
+``analyzer`` (with an empty stand-in module for the absent ``cv2``, which only
+``boundary_by_convex_hull`` touches), runs them on seeded synthetic inputs and
+writes ``tests/golden/*.npz``: inputs (or the seed + a SHA-256 of the input
+bytes when the input is large) and the reference's outputs.  Nothing else in
+the repository reads the reference.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import tempfile
+import types
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+
+warnings.simplefilter("ignore")
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+sys.path.insert(1, ROOT)
+os.chdir(tempfile.mkdtemp(prefix="pcfit_golden_"))      # the analyzer creates ./plots_slices
+
+from utils import circle_fitting as rcf      # noqa: E402  (reference)
+from utils import boundary as rbd            # noqa: E402  (reference)
+import analyzer as ran                       # noqa: E402  (reference)
+import scipy                                 # noqa: E402
+from oracle.ref_np import make_cylinder, make_slices   # noqa: E402  (input generators only)
+
+META = dict(numpy=np.__version__, scipy=scipy.__version__, python=sys.version.split()[0])
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, meta=np.array(repr(META)), **arrays)
+    print(f"{name}.npz  {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def ring(n, seed, r=10.0, c=(3.0, -2.0), sigma=0.05, arc=(0.0, 2 * np.pi), outlier=0.0):
+    g = np.random.default_rng(seed)
+    th = g.uniform(arc[0], arc[1], n)
+    rr = r + g.normal(0, sigma, n)
+    if outlier > 0:
+        bad = g.random(n) < outlier
+        rr[bad] = g.uniform(0, 1.4 * r, int(bad.sum()))
+    return np.stack([c[0] + rr * np.cos(th), c[1] + rr * np.sin(th)], axis=1)
+
+
+# 1. trial -> triple tables ------------------------------------------------
+def g_choice3():
+    out = {}
+    for n in (3, 4, 5, 7, 64, 86, 100, 257, 1000, 8192, 10001, 65537, 1000003):
+        g = np.random.default_rng(42)
+        out[f"n{n}"] = np.array([g.choice(n, size=3, replace=False) for _ in range(64)], dtype=np.int32)
+    g = np.random.default_rng(42)
+    out["n92_t4000"] = np.array([g.choice(92, size=3, replace=False) for _ in range(4000)], dtype=np.int32)
+    for seed in (0, 1, 7, 123456789, 2**40 + 5):
+        g = np.random.default_rng(seed)
+        out[f"seed{seed}_n500"] = np.array([g.choice(500, size=3, replace=False) for _ in range(32)], dtype=np.int32)
+    save("choice3", **out)
+
+
+# 2. three-point circles ---------------------------------------------------
+def g_circle3():
+    g = np.random.default_rng(11)
+    tri = g.normal(0, 10, (400, 3, 2))
+    tri[300:350, 2] = tri[300:350, 0] + (tri[300:350, 1] - tri[300:350, 0]) * g.uniform(0, 2, (50, 1)) \
+        + g.normal(0, 1e-9, (50, 2))                              # nearly collinear
+    tri[350:380, 2] = tri[350:380, 0] + (tri[350:380, 1] - tri[350:380, 0]) * 0.5   # collinear up to rounding
+    tri[380:] *= 1e-7                                             # tiny coordinates -> |det| < 1e-12
+    ok = np.zeros(400, bool)
+    val = np.full((400, 3), np.nan)
+    for i, t in enumerate(tri):
+        c = rcf._circle_from_3pts(t[0], t[1], t[2])
+        if c is not None:
+            ok[i] = True
+            val[i] = c
+    save("circle3", tri=tri, ok=ok, val=val)
+
+
+# 3 + 4. Kasa and LM ---------------------------------------------------------
+def fit_cases():
+    cases = [
+        ring(8192, 1), ring(8192, 2, outlier=0.3), ring(500, 3, arc=(0.3, 0.3 + np.pi / 2)),
+        ring(92, 4), ring(64, 5, sigma=0.5), ring(3, 6), ring(4000, 7, r=2.5, c=(-100.0, 250.0), sigma=0.01),
+        ring(1000, 8, r=1e3, c=(1e5, -2e5), sigma=1.0), ring(257, 9, outlier=0.1),
+        ring(5000, 10, arc=(0, np.pi / 8), sigma=0.02),
+        np.stack([np.linspace(0, 1, 50), 2 * np.linspace(0, 1, 50) + 1], axis=1) + np.random.default_rng(12).normal(0, 1e-3, (50, 2)),
+        np.concatenate([ring(40, 13, sigma=0.0)] * 3) + np.random.default_rng(14).normal(0, 1e-6, (120, 2)),
+    ]
+    return cases
+
+
+def g_kasa_lm():
+    out = {}
+    for i, xy in enumerate(fit_cases()):
+        out[f"xy{i}"] = xy
+        k = rcf.fit_circle_pratt(xy[:, 0], xy[:, 1])
+        out[f"kasa{i}"] = np.array(k)
+        out[f"lm{i}"] = np.array(rcf.lm_circle_geometric(xy[:, 0], xy[:, 1], *k))
+        out[f"lm_d02_{i}"] = np.array(rcf.lm_circle_geometric(xy[:, 0], xy[:, 1], *k, huber_delta=0.2))
+        off = (k[0] + 0.5, k[1] - 0.3, k[2] * 1.1)
+        out[f"lm_off{i}"] = np.array(rcf.lm_circle_geometric(xy[:, 0], xy[:, 1], *off, max_iter=25))
+    save("kasa_lm", **out)
+
+
+# 5. RANSAC ------------------------------------------------------------------
+def ransac_margin(xy, tol, trials, r_range=None):
+    """Replays the reference loop with the reference's own 3-point routine to
+    record which trial won and how close any point came to the tolerance."""
+    g = np.random.default_rng(42)
+    best, best_t, margin = -1, -1, np.inf
+    for t in range(trials):
+        idx = g.choice(len(xy), size=3, replace=False)
+        c = rcf._circle_from_3pts(xy[idx[0]], xy[idx[1]], xy[idx[2]])
+        if c is None:
+            continue
+        if r_range is not None and not (r_range[0] <= c[2] <= r_range[1]):
+            continue
+        dx = xy[:, 0] - c[0]
+        dy = xy[:, 1] - c[1]
+        err = np.abs(np.sqrt(dx * dx + dy * dy) - c[2])
+        margin = min(margin, float(np.abs(err - tol).min()))
+        s = int((err <= tol).sum())
+        if s > best:
+            best, best_t = s, t
+    return best_t, margin
+
+
+def g_ransac():
+    sets = [
+        (ring(60, 21), 0.5, 400, None, 0.1), (ring(92, 22, outlier=0.3), 0.5, 4000, None, 0.1),
+        (ring(300, 23, outlier=0.3), 0.5, 1024, None, 0.1), (ring(1000, 24, outlier=0.5), 0.3, 512, None, 0.1),
+        (ring(8192, 25, outlier=0.3), 0.5, 1024, None, 0.1), (ring(8192, 26), 0.5, 256, None, 0.1),
+        (ring(200, 27, outlier=0.3), 0.5, 600, (9.0, 11.0), 0.1), (ring(40, 28, outlier=0.9), 0.05, 300, None, 0.6),
+        (ring(5, 29), 0.5, 50, None, 0.1), (ring(3, 30), 0.5, 10, None, 0.1),
+        (ring(500, 31, outlier=0.3), 0.5, 200, (20.0, 30.0), 0.1),
+    ]
+    out = {}
+    for i, (xy, tol, trials, rr, frac) in enumerate(sets):
+        m = rcf._ransac_circle(xy, inlier_tol=tol, max_trials=trials, min_inliers_frac=frac, r_range=rr)
+        out[f"xy{i}"] = xy
+        out[f"par{i}"] = np.array([tol, trials, frac, -1 if rr is None else rr[0], -1 if rr is None else rr[1]])
+        if m is None:
+            out[f"ok{i}"] = np.array(False)
+            continue
+        bt, margin = ransac_margin(xy, tol, trials, rr)
+        out[f"ok{i}"] = np.array(True)
+        out[f"model{i}"] = np.array([m["cx"], m["cy"], m["R"]])
+        out[f"score{i}"] = np.array(m["score"])
+        out[f"mask{i}"] = m["mask"]
+        out[f"best_trial{i}"] = np.array(bt)
+        out[f"margin{i}"] = np.array(margin)
+    save("ransac", **out)
+
+
+# 6 + 7. unique / hull / hybrid ----------------------------------------------
+def slab(n, seed, outlier=0.0, dup=0, sigma=0.05):
+    xy = ring(n, seed, outlier=outlier, sigma=sigma)
+    g = np.random.default_rng(seed + 1000)
+    if dup:
+        xy = np.concatenate([xy, xy[g.integers(0, n, dup)]])
+    z = g.uniform(-0.9, 0.9, len(xy))
+    return np.column_stack([xy, z])
+
+
+def g_hull_hybrid():
+    from scipy.spatial import ConvexHull
+    cases = [slab(2000, 41), slab(5000, 42, outlier=0.3), slab(300, 43, dup=60), slab(1200, 44, outlier=0.05),
+             slab(64, 45), slab(3000, 46, sigma=0.2), slab(800, 47, outlier=0.6), slab(5, 48), slab(10, 49),
+             slab(1500, 50, outlier=0.01)]
+    out = {}
+    for i, pts in enumerate(cases):
+        out[f"pts{i}"] = pts
+        res = rcf.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=800)
+        keep = (pts[:, 2] >= -0.5) & (pts[:, 2] <= 0.5)
+        uniq = np.unique(pts[keep, :2], axis=0)
+        out[f"uniq{i}"] = uniq
+        out[f"qhull{i}"] = ConvexHull(uniq).vertices.astype(np.int64) if len(uniq) >= 3 else np.zeros(0, np.int64)
+        out[f"ok{i}"] = np.array(res is not None)
+        if res is not None:
+            out[f"fit{i}"] = np.array([res["center_x"], res["center_y"], res["radius"]])
+            out[f"mask{i}"] = res["inlier_mask"]
+            out[f"cand{i}"] = res["candidates_xy"]
+            assert np.array_equal(res["fit_points_xy"], uniq)
+    save("hull_hybrid", **out)
+
+
+# 8 + 9. boundaries / ovality / residual profile ------------------------------
+def g_boundary():
+    out = {}
+    for i, (xy, bins) in enumerate([(ring(8192, 61), 720), (ring(8192, 62, outlier=0.1), 720), (ring(3000, 63), 90),
+                                    (ring(50000, 64), 3600), (ring(400, 65, arc=(1.0, 2.5)), 720)]):
+        if len(xy) <= 8192:
+            out[f"xy{i}"] = xy
+        else:
+            out[f"xy{i}_sha"] = np.array(sha(xy))
+        b0 = rbd.boundary_by_angle_max(xy, bins=bins)                  # centre from the Kasa fit
+        b1 = rbd.boundary_by_angle_max(xy, center=(3.0, -2.0), bins=bins)
+        lut = {tuple(p): k for k, p in reversed(list(enumerate(map(tuple, xy))))}
+        out[f"bins{i}"] = np.array(bins)
+        out[f"idx_auto{i}"] = np.array([lut[tuple(p)] for p in b0], dtype=np.int64)
+        out[f"idx_c{i}"] = np.array([lut[tuple(p)] for p in b1], dtype=np.int64)
+    for i, xy in enumerate([ring(92, 71), ring(150, 72, sigma=0.2), ring(1500, 73), ring(10, 74)]):
+        fit = (3.01, -1.98, 10.02)
+        ov = rbd.ovality_and_fourier(xy[:, 0], xy[:, 1], *fit)
+        out[f"ov_xy{i}"] = xy
+        out[f"ov_fit{i}"] = np.array(fit)
+        out[f"ov_scal{i}"] = np.array([ov["Rmax"], ov["Rmin"], ov["ovality_abs"], ov["ovality_pct"], ov["k2_amp"]])
+        out[f"ov_dev{i}"] = ov["dev_uniform"]
+        # residual profile exactly as gui.py:979-987 writes it
+        dx = xy[:, 0] - fit[0]
+        dy = xy[:, 1] - fit[1]
+        th = (np.arctan2(dy, dx) + 2 * np.pi) % (2 * np.pi)
+        dr = np.hypot(dx, dy) - fit[2]
+        o = np.argsort(th)
+        out[f"rp_theta{i}"] = th[o]
+        out[f"rp_dr{i}"] = dr[o]
+    save("boundary", **out)
+
+
+# 10 + 11. analyzer -----------------------------------------------------------
+SCALARS = ["z_center", "z_low", "z_high", "n_points_slice", "n_edge", "cx", "cy", "R", "Rmax", "Rmin",
+           "x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin", "ovality_abs", "ovality_pct", "k2_amp", "cost"]
+
+
+def g_analyzer():
+    out = {}
+    pts = make_cylinder(50_000, 20, seed=5, outlier_frac=0.02)
+    # points exactly on shared window edges, below the first and above the last window
+    pts[10:40, 2] = np.repeat(np.arange(2.0, 32.0, 2.0), 2)
+    out["pts_sha"] = np.array(sha(pts))
+    out["gen"] = np.array([50_000, 20, 5, 0.02])
+    cfg = ran.Config(z_step=2.0, min_points_per_slice=1000)
+    az = ran.CylinderAnalyzer(cfg)
+    zc = az.calculate_z_centers(pts)
+    out["z_centers"] = zc
+    counts, first = [], []
+    for c in zc:
+        m = (pts[:, 2] >= c - 1.0) & (pts[:, 2] <= c + 1.0)
+        counts.append(int(m.sum()))
+        first.append(np.nonzero(m)[0][:16])
+    out["member_counts"] = np.array(counts)
+    out["member_first16"] = np.array(first)
+    prog = []
+    res = az.analyze_with_progress(pts, progress_callback=prog.append)
+    out["progress_sorted"] = np.array(sorted(prog))
+    out["n_results"] = np.array(len(res))
+    out["keys"] = np.array(list(res[0].keys()))
+    out["scalars"] = np.array([[r[k] for k in SCALARS] for r in res], dtype=float)
+    out["bpts_len"] = np.array([len(r["boundary_points"]) for r in res])
+    out["bpts_cat"] = np.concatenate([np.array(r["boundary_points"]) for r in res])
+    # one process_slice in full, including the edge frame
+    (r0, cand, slc, fit, ov), edge, warn = az.process_slice(pts, zc[3])
+    out["ps_scal"] = np.array([r0[k] for k in SCALARS], dtype=float)
+    out["ps_edge_cols"] = np.array(list(edge.columns))
+    out["ps_edge"] = edge.to_numpy(dtype=float)
+    out["ps_slc_len"] = np.array(len(slc))
+    sparse = az.process_slice(pts[:500], zc[3])
+    out["ps_sparse_msg"] = np.array(sparse[2])
+    # configured z range: centres come from the config, not the data
+    az2 = ran.CylinderAnalyzer(ran.Config(z_step=4.0, min_points_per_slice=100, z_min=3.0, z_max=29.0))
+    res2 = az2.analyze_with_progress(pts)
+    out["cfg_z_centers"] = az2.calculate_z_centers(pts)
+    out["cfg_scalars"] = np.array([[r[k] for k in SCALARS] for r in res2], dtype=float)
+    save("analyzer", **out)
+
+
+if __name__ == "__main__":
+    g_choice3()
+    g_circle3()
+    g_kasa_lm()
+    g_ransac()
+    g_hull_hybrid()
+    g_boundary()
+    g_analyzer()
