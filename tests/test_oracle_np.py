@@ -162,7 +162,7 @@ def test_analyzer_slicing_and_results():
     fit = [SCALARS.index(k) for k in ("cx", "cy", "R")]
     dev = np.abs(mine[:, fit] - ref[:, fit]).max(axis=1) / ref[:, SCALARS.index("R")]
     assert np.median(dev) < 1e-9
-    assert np.count_nonzero(dev > 1e-9) <= 2 and dev.max() < 0.05     # slices whose hull holds outliers
+    assert np.count_nonzero(dev > 1e-9) <= 4 and dev.max() < 0.05     # slices whose hull holds outliers
     off = 0
     for r, n in zip(res, g["bpts_len"]):
         want = [tuple(p) for p in g["bpts_cat"][off:off + n]]
