@@ -1,0 +1,232 @@
+/*
+ * pcfit.h - C ABI of libpcfit_hip.so: the slice -> circle fit -> boundary ->
+ * residual path of a cylinder point-cloud analyzer on MI355X (gfx950).
+ *
+ * The reference this replaces is pure Python and has no FFI of its own; its
+ * boundary is a set of Python functions.  Each entry point below names the
+ * reference function (file:line, relative to the reference checkout) whose
+ * arithmetic it performs for a whole batch of slices.  The Python drop-in
+ * (pointcloud_amd/) binds these with ctypes.
+ *
+ * Conventions
+ *  - Plain C: pointers and sizes only.  Functions return 0 (PCFIT_OK) or a
+ *    negative PCFIT_ERR_* code; pcfit_last_error() gives the text for the
+ *    calling thread.  Nothing throws, nothing aborts.
+ *  - Slices are CSR segments: point i of slice s is (x[offsets[s]+i],
+ *    y[offsets[s]+i]), offsets has S+1 int64 entries.
+ *  - "_dev" entry points take DEVICE pointers and a HIP stream handle
+ *    (hipStream_t cast to void*, NULL = default stream).  They enqueue work and
+ *    return; they never allocate, free or synchronise.  Scratch memory comes
+ *    from the caller (pcfit_*_workspace_bytes tells how much).
+ *  - Entry points without "_dev" take HOST pointers (numpy buffers): they
+ *    allocate device memory, copy in, run the same kernels, copy out,
+ *    synchronise and free.  They are re-entrant; no global mutable state.
+ *  - Per-slice status codes (int32): 0 ok, 1 too few points, 2 no 2-D
+ *    variation (rank deficient), 3 RANSAC consensus below the minimum,
+ *    4 singular system.
+ *  - Everything is FP64; indices are int64 (slice-local unless stated),
+ *    masks uint8.
+ */
+#ifndef PCFIT_H
+#define PCFIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCFIT_OK 0
+#define PCFIT_ERR_INVALID (-1)     /* bad argument */
+#define PCFIT_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define PCFIT_ERR_WORKSPACE (-3)   /* workspace missing or too small */
+#define PCFIT_ERR_UNSUPPORTED (-4) /* size beyond what the kernels handle */
+
+#define PCFIT_ST_OK 0
+#define PCFIT_ST_SPARSE 1
+#define PCFIT_ST_RANK 2
+#define PCFIT_ST_RANSAC 3
+#define PCFIT_ST_SINGULAR 4
+
+/* ---- library / device plumbing -------------------------------------- */
+int pcfit_version(void);
+const char *pcfit_last_error(void);
+int pcfit_device_count(int *count);
+int pcfit_set_device(int device);
+int pcfit_malloc(void **ptr, size_t bytes);
+int pcfit_free(void *ptr);
+int pcfit_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
+int pcfit_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int pcfit_memset(void *dst_dev, int value, size_t bytes, void *stream);
+int pcfit_stream_synchronize(void *stream);
+
+/* ---- RANSAC sampling tables (host side, exact integer work) --------- */
+/* PCG64 state numpy's default_rng(seed) starts from: state_hi, state_lo,
+ * inc_hi, inc_lo.  circle_fitting.py:124. */
+int pcfit_seed_state(uint64_t seed, uint64_t state[4]);
+/* The index triples rng.choice(n, size=3, replace=False) returns on calls
+ * 0..trials-1 (circle_fitting.py:126).  The draw precedes every rejection, so
+ * the table depends on (state, n, trials) only.  out: trials*3 int32. */
+int pcfit_choice3_table(const uint64_t state[4], int64_t n, int32_t trials, int32_t *out);
+
+/* ---- slice binning: analyzer.py:49-52 -------------------------------- */
+/* xyz: N rows of (x, y, z).  Window s is the closed interval
+ * [z_lo[s], z_hi[s]]; windows are ascending and near-uniform (as
+ * analyzer.py:240-243 builds them); a point may lie in up to two consecutive
+ * windows (shared closed edge) or in none.  Step 1 counts: offsets[S+1] is the
+ * exclusive prefix sum of the window populations (device memory).  Step 2
+ * scatters x and y slice after slice, keeping the original order inside a
+ * slice (what points[mask] gives); perm (nullable) receives the source row of
+ * every output point.  x_out/y_out/perm must hold offsets[S] entries.
+ * window_geom: three doubles in HOST memory, {z_lo[0], z_hi[0], z_lo[S-1]}
+ * (the device arrays decide membership; these only locate the candidate
+ * window).  At most 16384 windows per call.  The same workspace must be passed
+ * to both steps. */
+size_t pcfit_bin_workspace_bytes(int64_t n_points, int64_t n_slices);
+int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                        int64_t n_slices, const double *window_geom, int64_t *offsets, void *workspace,
+                        size_t workspace_bytes, void *stream);
+int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                          int64_t n_slices, const double *window_geom, const int64_t *offsets, double *x_out,
+                          double *y_out, int64_t *perm, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- algebraic fit: fit_circle_pratt, circle_fitting.py:35-54 -------- */
+/* cxcyr: S*3 (cx, cy, R).  status (nullable): 0, 1 (n < 3) or 4 (exactly
+ * singular normal equations: the minimum-norm solution is returned, as the
+ * reference's lstsq fallback does).  max_slice_len: largest slice population
+ * (lets the launch keep a slice in registers); 0 if unknown. */
+int pcfit_kasa_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                         int64_t max_slice_len, double *cxcyr, int32_t *status, void *stream);
+
+/* ---- geometric refinement: lm_circle_geometric, circle_fitting.py:57-109 */
+/* init, out: S*3.  iters (nullable): S*2 = {iterations of the reference loop,
+ * accepted steps}.  max_slice_len: largest slice population (lets the launch
+ * keep a slice in registers); pass 0 if unknown. */
+int pcfit_lm_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                       int64_t max_slice_len, const double *init, double huber_delta, int32_t max_iter,
+                       double lm_lambda0, double tol_update, double tol_cost, double *out, int32_t *iters,
+                       void *stream);
+
+/* Kasa start then LM in one launch, each slice read from HBM once
+ * (circle_fitting.py:217-222 chains the two the same way).  kasa_out, iters,
+ * status nullable. */
+int pcfit_fit_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                        int64_t max_slice_len, double huber_delta, int32_t max_iter, double lm_lambda0,
+                        double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
+                        int32_t *status, void *stream);
+
+/* ---- RANSAC: _ransac_circle, circle_fitting.py:112-143 --------------- */
+/* triples: n_tables tables of trials*3 int32 (pcfit_choice3_table), device
+ * memory; table_of_slice[s] selects the table built for that slice's n.
+ * r_range: NULL or two doubles in HOST memory.  Outputs: model S*3, score S
+ * (-1 when no trial produced a circle), best_trial S, mask one byte per point
+ * (same CSR layout as x), status S (0, 1 or 3).  The earliest trial of
+ * maximal score wins. */
+size_t pcfit_ransac_workspace_bytes(int64_t n_slices);
+int pcfit_ransac_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                           double inlier_tol, int32_t trials, double min_inliers_frac, const double *r_range,
+                           const int32_t *triples, const int32_t *table_of_slice, double *model, int32_t *score,
+                           int32_t *best_trial, uint8_t *mask, int32_t *status, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ---- residual profile + histogram: gui.py:972-987, analyzer.py:83-92 -- */
+/* Per point theta = (atan2 + 2pi) mod 2pi, dr = hypot - R and radius = hypot
+ * (each output nullable); per slice numpy.histogram(dr, bins=H, range=(edges[0], edges[H]))
+ * with the H+1 edges given (device memory; H may be 0), Rmax/Rmin and the first
+ * slice-local index attaining each. */
+int pcfit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                              const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
+                              const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin,
+                              void *stream);
+
+/* ---- boundary by angular bins: boundary_by_angle_max, boundary.py:7-42 - */
+/* sel: S*bins; the slice-local index of the first point of largest radius in
+ * each angular bin about (cx, cy) = cxcyr[3s], cxcyr[3s+1], or -1. */
+int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                              const double *cxcyr, int32_t bins, int64_t *sel, void *stream);
+
+/* ---- unique rows, rank check, hull: circle_fitting.py:14-19, 182-198 -- */
+/* ux, uy: the slice's distinct points sorted by (x, y), written at the slice's
+ * own CSR offset; n_unique[s] of them.  hull_idx (same CSR capacity): indices
+ * into the slice's unique array of its strictly convex hull, counter-
+ * clockwise, starting at index 0 or, when hull_start (nullable, S entries,
+ * -1 = default) names a hull vertex, at that vertex.  n_hull[s] = 0 and
+ * status 2 when the unique points have no 2-D variation; status 1 when fewer
+ * than 3 points. */
+size_t pcfit_unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices);
+int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                int64_t max_slice_len, double *ux, double *uy, int64_t *n_unique,
+                                int64_t *hull_idx, int64_t *n_hull, int32_t *status, const int64_t *hull_start,
+                                void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- ovality + k=2 Fourier amplitude: ovality_and_fourier, boundary.py:56-90 */
+/* scal: S*5 = Rmax, Rmin, ovality_abs, ovality_pct, k2_amp (NaN for an empty
+ * slice or a NaN circle).  dev_uniform (nullable): row s holds the deviation
+ * profile resampled on K_s = max(1024, n_s) uniform angles; rows are grid_len
+ * apart, grid_len >= max(1024, longest slice).  Slices of at most 8192 points. */
+int pcfit_ovality_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                            int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
+                            int64_t grid_len, void *stream);
+
+/* ---- host-pointer convenience forms (numpy in, numpy out) ------------ */
+int pcfit_kasa_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double *cxcyr,
+                     int32_t *status);
+int pcfit_lm_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, const double *init,
+                   double huber_delta, int32_t max_iter, double lm_lambda0, double tol_update, double tol_cost,
+                   double *out, int32_t *iters);
+int pcfit_ransac_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                       double inlier_tol, int32_t trials, double min_inliers_frac, const double *r_range,
+                       uint64_t seed, double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
+                       int32_t *status);
+int pcfit_residuals_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                          const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
+                          const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin);
+int pcfit_angle_max_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                          const double *cxcyr, int32_t bins, int64_t *sel);
+/* offsets: S+1 out; x_out/y_out/perm: capacity entries (2*N always suffices);
+ * *total receives offsets[S].  Returns PCFIT_ERR_INVALID if capacity is short. */
+int pcfit_bin_slices(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
+                     int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
+                     int64_t *total);
+int pcfit_unique_hull_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double *ux,
+                            double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull, int32_t *status,
+                            const int64_t *hull_start);
+int pcfit_ovality_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                        const double *cxcyr, double *scal, double *dev_uniform, int64_t grid_len);
+
+/* _has_enough_2d_variation (circle_fitting.py:14-19) per slice: ok[s] = 1 when
+ * the second singular value of the centred points exceeds eps*(first + eps). */
+int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double eps,
+                           uint8_t *ok);
+/* _circle_from_3pts (circle_fitting.py:22-32) for n_triples rows of
+ * {x1,y1,x2,y2,x3,y3}: out n_triples*3 (cx, cy, R), ok 0 where |det| < 1e-12. */
+int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, uint8_t *ok);
+
+/* ---- the whole hybrid fit for a batch of slices ----------------------- */
+/* fit_circle_hybrid_at_z (circle_fitting.py:146-232) for S slices whose points
+ * are already cut to their z window, followed by the per-slice metrics of
+ * CylinderAnalyzer.process_slice (analyzer.py:83-95).  Host pointers.
+ * In: r_range NULL or 2 doubles; use_hull = use_hull_vertices_only;
+ *     hull_start NULL or S entries (-1 = walk the hull from its lexicographic
+ *     minimum; otherwise the index, in the slice's unique array, of the vertex
+ *     to start from - lets a caller replay Qhull's order).
+ * Out (capacity of every per-point array = offsets[S]):
+ *     status S (0 ok / 1 / 2 / 3: the reference returns None), fit S*3,
+ *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy),
+ *     cand_offsets S+1, cand_x, cand_y, mask     candidates_xy and inlier_mask,
+ *     radius, theta              hypot and angle of every candidate about the fit,
+ *     argmax_argmin S*2          candidate indices of the largest / smallest radius,
+ *     ov_scal S*5, dev_uniform (nullable, rows grid_len apart)   ovality_and_fourier. */
+int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                       double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
+                       double huber_delta, int32_t use_hull, const int64_t *hull_start, uint64_t seed,
+                       int32_t *status, double *fit, double *ux, double *uy, int64_t *n_unique,
+                       int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
+                       double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
+                       int64_t grid_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCFIT_H */

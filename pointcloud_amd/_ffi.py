@@ -1,0 +1,288 @@
+"""ctypes binding of libpcfit_hip.so (the C ABI declared in include/pcfit.h).
+
+There is no CPU fallback: if the shared library is missing, or a call fails,
+an exception is raised.  Host-pointer entry points take numpy arrays; the
+``*_dev`` entry points are exposed raw (``lib().pcfit_*_dev``) for callers that
+manage device memory themselves (bench.py does, through torch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libpcfit_hip.so")
+
+
+class PcfitError(RuntimeError):
+    pass
+
+
+_lib = None
+
+c_f64p = C.POINTER(C.c_double)
+_vp = C.c_void_p
+_i64 = C.c_int64
+_i32 = C.c_int32
+_f64 = C.c_double
+_sz = C.c_size_t
+_u64 = C.c_uint64
+
+# name -> (restype, argtypes); every symbol include/pcfit.h declares
+SIGNATURES = {
+    "pcfit_version": (C.c_int, []),
+    "pcfit_last_error": (C.c_char_p, []),
+    "pcfit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pcfit_set_device": (C.c_int, [C.c_int]),
+    "pcfit_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
+    "pcfit_free": (C.c_int, [_vp]),
+    "pcfit_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "pcfit_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "pcfit_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),
+    "pcfit_stream_synchronize": (C.c_int, [_vp]),
+    "pcfit_seed_state": (C.c_int, [_u64, _vp]),
+    "pcfit_choice3_table": (C.c_int, [_vp, _i64, _i32, _vp]),
+    "pcfit_bin_workspace_bytes": (_sz, [_i64, _i64]),
+    "pcfit_bin_count_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pcfit_bin_scatter_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcfit_kasa_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "pcfit_lm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp]),
+    "pcfit_fit_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
+                                      _vp]),
+    "pcfit_ransac_workspace_bytes": (_sz, [_i64]),
+    "pcfit_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _sz, _vp]),
+    "pcfit_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pcfit_angle_max_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "pcfit_unique_hull_workspace_bytes": (_sz, [_i64, _i64]),
+    "pcfit_unique_hull_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                              _vp]),
+    "pcfit_ovality_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "pcfit_kasa_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "pcfit_lm_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp]),
+    "pcfit_ransac_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "pcfit_residuals_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "pcfit_angle_max_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp]),
+    "pcfit_bin_slices": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "pcfit_unique_hull_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pcfit_ovality_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "pcfit_rank_check_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
+    "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
+                           + [_i64]),
+}
+
+
+def lib():
+    """Load libpcfit_hip.so once; raise if it is not there (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise PcfitError(
+                f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise PcfitError(f"pcfit error {rc}: {lib().pcfit_last_error().decode(errors='replace')}")
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data
+
+
+def as_csr(x, y, offsets):
+    x = _arr(x, np.float64).ravel()
+    y = _arr(y, np.float64).ravel()
+    if offsets is None:
+        offsets = np.array([0, x.size], dtype=np.int64)
+    offsets = _arr(offsets, np.int64)
+    if x.size != y.size or offsets[-1] != x.size or offsets[0] != 0:
+        raise ValueError("x, y and offsets do not describe the same points")
+    return x, y, offsets
+
+
+# ---------------------------------------------------------------- host calls
+def seed_state(seed: int) -> np.ndarray:
+    out = np.zeros(4, np.uint64)
+    check(lib().pcfit_seed_state(int(seed) & (2**64 - 1), _p(out)))
+    return out
+
+
+def seed_state_from_numpy(seed) -> np.ndarray:
+    """PCG64 state for any seed numpy accepts (numpy does the seeding)."""
+    st = np.random.PCG64(seed).state["state"]
+    m = 2**64 - 1
+    return np.array([st["state"] >> 64, st["state"] & m, st["inc"] >> 64, st["inc"] & m], dtype=np.uint64)
+
+
+def choice3_table(n: int, trials: int, seed=42) -> np.ndarray:
+    out = np.zeros((trials, 3), np.int32)
+    if isinstance(seed, (int, np.integer)) and 0 <= int(seed) < 2**64:
+        state = seed_state(seed)
+    else:
+        state = seed_state_from_numpy(seed)
+    check(lib().pcfit_choice3_table(_p(state), n, trials, _p(out)))
+    return out
+
+
+def kasa_batch(x, y, offsets=None):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    out = np.full((S, 3), np.nan)
+    status = np.zeros(S, np.int32)
+    check(lib().pcfit_kasa_batch(_p(x), _p(y), _p(offsets), S, _p(out), _p(status)))
+    return out, status
+
+
+def lm_batch(x, y, offsets, init, huber_delta=1.0, max_iter=100, lm_lambda0=1e-2, tol_update=1e-10, tol_cost=1e-12):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    init = _arr(init, np.float64).reshape(S, 3)
+    out = np.zeros((S, 3))
+    iters = np.zeros((S, 2), np.int32)
+    check(lib().pcfit_lm_batch(_p(x), _p(y), _p(offsets), S, _p(init), huber_delta, max_iter, lm_lambda0, tol_update,
+                               tol_cost, _p(out), _p(iters)))
+    return out, iters
+
+
+def ransac_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None, seed=42):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    model = np.zeros((S, 3))
+    score = np.zeros(S, np.int32)
+    best = np.zeros(S, np.int32)
+    mask = np.zeros(max(x.size, 1), np.uint8)
+    status = np.zeros(S, np.int32)
+    rr = None if r_range is None else _arr(r_range, np.float64)
+    check(lib().pcfit_ransac_batch(_p(x), _p(y), _p(offsets), S, inlier_tol, max_trials, min_inliers_frac, _p(rr),
+                                   int(seed), _p(model), _p(score), _p(best), _p(mask), _p(status)))
+    return dict(model=model, score=score, best_trial=best, mask=mask[:x.size].astype(bool), status=status)
+
+
+def residuals_batch(x, y, offsets, cxcyr, bins=0, lo=0.0, hi=1.0, want_theta=True, want_dr=True, want_radius=False):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    fit = _arr(cxcyr, np.float64).reshape(S, 3)
+    theta = np.zeros(x.size) if want_theta else None
+    dr = np.zeros(x.size) if want_dr else None
+    rad = np.zeros(x.size) if want_radius else None
+    edges = np.linspace(lo, hi, bins + 1) if bins > 0 else None      # numpy.histogram's own edges
+    hist = np.zeros((S, bins), np.int64) if bins > 0 else None
+    rmm = np.zeros((S, 2))
+    amm = np.zeros((S, 2), np.int64)
+    check(lib().pcfit_residuals_batch(_p(x), _p(y), _p(offsets), S, _p(fit), _p(theta), _p(dr), _p(rad), bins,
+                                      _p(edges), _p(hist), _p(rmm), _p(amm)))
+    return dict(theta=theta, dr=dr, radius=rad, hist=hist, rmax=rmm[:, 0], rmin=rmm[:, 1], argmax=amm[:, 0], argmin=amm[:, 1])
+
+
+def angle_max_batch(x, y, offsets, cxcyr, bins=720):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    fit = _arr(cxcyr, np.float64).reshape(S, 3)
+    sel = np.zeros((S, bins), np.int64)
+    check(lib().pcfit_angle_max_batch(_p(x), _p(y), _p(offsets), S, _p(fit), bins, _p(sel)))
+    return sel
+
+
+def bin_slices(points, z_lo, z_hi, want_perm=True):
+    pts = _arr(points, np.float64)
+    if pts.ndim != 2 or pts.shape[1] != 3:
+        raise ValueError("points must be (N,3)")
+    z_lo = _arr(z_lo, np.float64)
+    z_hi = _arr(z_hi, np.float64)
+    S = z_lo.size
+    cap = 2 * pts.shape[0] + 1
+    offsets = np.zeros(S + 1, np.int64)
+    xo, yo = np.zeros(cap), np.zeros(cap)
+    perm = np.zeros(cap, np.int64) if want_perm else None
+    total = C.c_int64(0)
+    check(lib().pcfit_bin_slices(_p(pts), pts.shape[0], _p(z_lo), _p(z_hi), S, _p(offsets), _p(xo), _p(yo), _p(perm),
+                                 cap, C.addressof(total)))
+    t = total.value
+    return offsets, xo[:t], yo[:t], (perm[:t] if want_perm else None)
+
+
+def unique_hull_batch(x, y, offsets=None, hull_start=None):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    ux, uy = np.zeros(max(x.size, 1)), np.zeros(max(x.size, 1))
+    nu = np.zeros(S, np.int64)
+    hidx = np.zeros(max(x.size, 1), np.int64)
+    nh = np.zeros(S, np.int64)
+    status = np.zeros(S, np.int32)
+    hs = None if hull_start is None else _arr(hull_start, np.int64)
+    check(lib().pcfit_unique_hull_batch(_p(x), _p(y), _p(offsets), S, _p(ux), _p(uy), _p(nu), _p(hidx), _p(nh),
+                                        _p(status), _p(hs)))
+    return dict(ux=ux, uy=uy, n_unique=nu, hull_idx=hidx, n_hull=nh, status=status, offsets=offsets)
+
+
+def ovality_batch(x, y, offsets, cxcyr, want_profile=True):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    fit = _arr(cxcyr, np.float64).reshape(S, 3)
+    K = int(max(1024, np.diff(offsets).max() if S else 0))
+    scal = np.zeros((S, 5))
+    dev = np.zeros((S, K)) if want_profile else None
+    check(lib().pcfit_ovality_batch(_p(x), _p(y), _p(offsets), S, _p(fit), _p(scal), _p(dev), K))
+    return scal, dev
+
+
+def rank_check_batch(x, y, offsets=None, eps=1e-12):
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    ok = np.zeros(S, np.uint8)
+    check(lib().pcfit_rank_check_batch(_p(x), _p(y), _p(offsets), S, eps, _p(ok)))
+    return ok.astype(bool)
+
+
+def circle3_batch(triples):
+    tri = _arr(triples, np.float64).reshape(-1, 6)
+    out = np.zeros((tri.shape[0], 3))
+    ok = np.zeros(tri.shape[0], np.uint8)
+    check(lib().pcfit_circle3_batch(_p(tri), tri.shape[0], _p(out), _p(ok)))
+    return out, ok.astype(bool)
+
+
+def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
+                 huber_delta=1.0, use_hull=True, hull_start=None, seed=42, want_profile=True):
+    """fit_circle_hybrid_at_z + the metrics of process_slice for every slice of a CSR batch."""
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    tot = max(int(x.size), 1)
+    status = np.zeros(S, np.int32)
+    fit = np.full((S, 3), np.nan)
+    ux, uy = np.zeros(tot), np.zeros(tot)
+    n_unique = np.zeros(S, np.int64)
+    cand_off = np.zeros(S + 1, np.int64)
+    cx_, cy_ = np.zeros(tot), np.zeros(tot)
+    mask = np.zeros(tot, np.uint8)
+    radius, theta = np.zeros(tot), np.zeros(tot)
+    amm = np.zeros((S, 2), np.int64)
+    ov = np.zeros((S, 5))
+    K = int(max(1024, np.diff(offsets).max() if S else 0))
+    dev = np.full((S, K), np.nan) if want_profile else None
+    rr = None if r_range is None else _arr(r_range, np.float64)
+    hs = None if hull_start is None else _arr(hull_start, np.int64)
+    check(lib().pcfit_hybrid_batch(_p(x), _p(y), _p(offsets), S, inlier_tol, max_trials, min_inliers_frac, _p(rr),
+                                   huber_delta, 1 if use_hull else 0, _p(hs), int(seed), _p(status), _p(fit), _p(ux),
+                                   _p(uy), _p(n_unique), _p(cand_off), _p(cx_), _p(cy_), _p(mask), _p(radius),
+                                   _p(theta), _p(amm), _p(ov), _p(dev), K))
+    nc = int(cand_off[-1])
+    return dict(status=status, fit=fit, ux=ux, uy=uy, n_unique=n_unique, offsets=offsets, cand_offsets=cand_off,
+                cand_x=cx_[:nc], cand_y=cy_[:nc], mask=mask[:nc].astype(bool), radius=radius[:nc], theta=theta[:nc],
+                argmax=amm[:, 0], argmin=amm[:, 1], ov=ov, dev_uniform=dev, grid_len=K)

@@ -1,0 +1,211 @@
+"""Cylinder analysis driver with the reference's interface (reference:
+analyzer.py).  ``Config`` and ``CylinderAnalyzer`` keep their fields, method
+names, argument meaning, return types and error messages; underneath, all
+slices of a scan go through the GPU in one batch: stable slice binning, then the
+hybrid fit and the per-slice metrics (see include/pcfit.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _ffi
+from .utils.data_io import load_txt_points, save_results
+
+
+@dataclass
+class Config:
+    """Analysis configuration parameters (reference: analyzer.py:17-30).  Only
+    z_step, min_points_per_slice, max_points_for_speed, z_min and z_max influence
+    the numbers; the other fields are accepted for compatibility."""
+    z_step: float = 2.0
+    max_points_for_speed: int = 1_000_000
+    min_points_per_slice: int = 1000
+    inlier_quantile: float = 0.80
+    boundary_method: str = 'angle_max'
+    angle_bins: int = 720
+    draw_per_slice_images: bool = True
+    slice_plot_sample_points: int = 30000
+    overlay_all: bool = True
+    z_min: Optional[float] = None
+    z_max: Optional[float] = None
+
+
+# fit parameters the reference hard-codes in process_slice (analyzer.py:67-71)
+_FIT = dict(inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, huber_delta=1.0, use_hull=True)
+
+
+class CylinderAnalyzer:
+    def __init__(self, config: Config = None):
+        self.config = config or Config()
+        self.z_min = self.config.z_min
+        self.z_max = self.config.z_max
+        # output names of the reference (analyzer.py:38-41); nothing is created on disk here
+        self.slice_fig_dir = 'plots_slices'
+        self.results_csv = 'slice_results.csv'
+        self.points_csv = 'slice_points.csv'
+        self.overlay_png = 'all_circles_overlay.png'
+
+    # ------------------------------------------------------------------ batch core
+    def _run_windows(self, points: np.ndarray, z_centers: np.ndarray, hull_start=None, want_profile=True):
+        """Bin ``points`` into the closed windows around ``z_centers`` and run the
+        hybrid fit on every window.  Returns (offsets, x, y, hybrid-dict)."""
+        dz = self.config.z_step / 2.0
+        z_centers = np.asarray(z_centers, float)
+        offsets, x, y, _ = _ffi.bin_slices(points, z_centers - dz, z_centers + dz, want_perm=False)
+        h = _ffi.hybrid_batch(x, y, offsets, _FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None,
+                              _FIT["huber_delta"], _FIT["use_hull"], hull_start, want_profile=want_profile)
+        return offsets, x, y, h
+
+    def _slice_result(self, s: int, z_center, n0: int, h: dict):
+        """Result dict, edge frame columns and the ovality dict of slice ``s``
+        (reference: analyzer.py:77-127)."""
+        dz = self.config.z_step / 2.0
+        c0, c1 = int(h["cand_offsets"][s]), int(h["cand_offsets"][s + 1])
+        cand = np.stack([h["cand_x"][c0:c1], h["cand_y"][c0:c1]], axis=1)
+        cx, cy, R = (float(v) for v in h["fit"][s])
+        i_max, i_min = int(h["argmax"][s]), int(h["argmin"][s])
+        ovs = h["ov"][s]
+        K = max(1024, c1 - c0)
+        ov = {
+            "Rmax": np.float64(ovs[0]), "Rmin": np.float64(ovs[1]),
+            "ovality_abs": np.float64(ovs[2]), "ovality_pct": np.float64(ovs[3]), "k2_amp": np.float64(ovs[4]),
+            "theta": np.linspace(0, 2 * np.pi, K, endpoint=False),
+            "dev_uniform": None if h["dev_uniform"] is None else h["dev_uniform"][s, :K],
+        }
+        result = {
+            "z_center": z_center,
+            "z_low": z_center - dz,
+            "z_high": z_center + dz,
+            "n_points_slice": int(n0),
+            "n_edge": int(len(cand)),
+            "cx": cx, "cy": cy, "R": R,
+            "Rmax": ov["Rmax"],
+            "Rmin": ov["Rmin"],
+            "x_at_Rmax": float(cand[i_max, 0]),
+            "y_at_Rmax": float(cand[i_max, 1]),
+            "x_at_Rmin": float(cand[i_min, 0]),
+            "y_at_Rmin": float(cand[i_min, 1]),
+            "ovality_abs": ov["ovality_abs"],
+            "ovality_pct": ov["ovality_pct"],
+            "k2_amp": ov["k2_amp"],
+            "cost": 0.0,
+            "boundary_points": cand.tolist(),
+        }
+        edge = {
+            "z_center": z_center,
+            "x": cand[:, 0],
+            "y": cand[:, 1],
+            "radius": h["radius"][c0:c1],
+            "theta": h["theta"][c0:c1],
+            "inlier": h["mask"][c0:c1].astype(int),
+        }
+        return result, cand, (cx, cy, R), ov, edge
+
+    # ------------------------------------------------------------------ reference API
+    def process_slice(self, points: np.ndarray, z_center: float, *, hull_start: Optional[int] = None
+                      ) -> Tuple[dict, "pd.DataFrame", str]:  # noqa: F821
+        """Process a single slice of points (reference: analyzer.py:46-129)."""
+        import pandas as pd
+
+        points = np.asarray(points, float)
+        hs = None if hull_start is None else np.array([hull_start], np.int64)
+        offsets, x, y, h = self._run_windows(points, np.array([z_center], float), hs)
+        n0 = int(offsets[1])
+        if n0 < self.config.min_points_per_slice:
+            return None, None, f"SKIP zc={z_center:.3f}: too sparse ({n0} points)"
+        slc = np.stack([x, y], axis=1)
+        if n0 > self.config.max_points_for_speed:
+            # the reference thins only what it hands back for plotting; the fit sees every point
+            idx = np.random.choice(n0, self.config.max_points_for_speed, replace=False)
+            slc = slc[idx]
+            n0 = len(slc)
+        if h["status"][0] != 0:
+            return None, None, f"SKIP zc={z_center:.3f}: hybrid fit failed"
+        result, cand, fit, ov, edge = self._slice_result(0, z_center, n0, h)
+        return (result, cand, slc, fit, ov), pd.DataFrame(edge), None
+
+    def analyze_file(self, file_path: str):
+        """Process entire point cloud file (reference: analyzer.py:131-179).  Writes
+        slice_results.csv and slice_points.csv into the working directory; the
+        reference's matplotlib figures are not produced."""
+        import pandas as pd
+
+        points = load_txt_points(file_path)
+        z_min, z_max = points[:, 2].min(), points[:, 2].max()
+        print(f"Z range in data: [{z_min:.3f}, {z_max:.3f}]  "
+              f"| step={self.config.z_step}")
+        dz = self.config.z_step / 2.0
+        z_centers = np.arange(z_min + dz, z_max - dz + 1e-9, self.config.z_step)
+        results, frames = [], []
+        for res, edge, warn in self._analyze_windows(points, z_centers, want_edges=True):
+            if warn is not None:
+                print(warn)
+                continue
+            results.append(res)
+            frames.append(pd.DataFrame(edge))
+        if results:
+            save_results(results, frames, ".")
+        return results
+
+    def _analyze_windows(self, points, z_centers, want_edges=False):
+        """Yield (result, edge columns or None, warning) per window, in window order."""
+        if len(z_centers) == 0:
+            return
+        offsets, x, y, h = self._run_windows(points, z_centers, want_profile=False)
+        counts = np.diff(offsets)
+        for s, zc in enumerate(z_centers):
+            n0 = int(counts[s])
+            if n0 < self.config.min_points_per_slice:
+                yield None, None, f"SKIP zc={zc:.3f}: too sparse ({n0} points)"
+                continue
+            if h["status"][s] != 0:
+                yield None, None, f"SKIP zc={zc:.3f}: hybrid fit failed"
+                continue
+            n0 = min(n0, self.config.max_points_for_speed)
+            result, _, _, _, edge = self._slice_result(s, zc, n0, h)
+            yield result, (edge if want_edges else None), None
+
+    def analyze_with_progress(self, points: np.ndarray, progress_callback=None):
+        """Analyze points with progress reporting (reference: analyzer.py:181-230).
+        All windows run in one GPU batch; the callback then receives the same
+        integer percentages the reference's thread pool would emit."""
+        if not isinstance(points, np.ndarray):
+            points = np.array(points)
+
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("Points must be Nx3 array")
+
+        if self.z_min is not None and self.z_max is not None:
+            mask = (points[:, 2] >= self.z_min) & (points[:, 2] <= self.z_max)
+            points = points[mask]
+            if len(points) == 0:
+                raise ValueError(f"No points in specified Z range [{self.z_min}, {self.z_max}]")
+
+        results = []
+        z_centers = self.calculate_z_centers(points)
+        total = len(z_centers)
+        done = 0
+        for res, _, warn in self._analyze_windows(np.ascontiguousarray(points, dtype=np.float64), z_centers):
+            if warn is None:
+                results.append(res)
+            done += 1
+            if progress_callback:
+                progress_callback(int(done / total * 100))
+
+        results.sort(key=lambda r: r['z_center'])
+        return results
+
+    def calculate_z_centers(self, points: np.ndarray) -> np.ndarray:
+        """Calculate z-centers for slicing (reference: analyzer.py:232-243)."""
+        if self.z_min is not None and self.z_max is not None:
+            z_min, z_max = self.z_min, self.z_max
+        else:
+            z_min, z_max = points[:, 2].min(), points[:, 2].max()
+
+        dz = self.config.z_step / 2.0
+        return np.arange(z_min + dz,
+                         z_max - dz + 1e-9,
+                         self.config.z_step)

@@ -1,0 +1,371 @@
+// Library plumbing, RANSAC sampling tables (host, integer work) and the
+// host-pointer convenience entry points of libpcfit_hip.so.
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "pcfit_internal.h"
+
+namespace pcfit {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// ---- numpy SeedSequence -> PCG64, Generator.choice(n, 3, replace=False) ----
+typedef unsigned __int128 u128;
+static const u128 PCG_MULT = ((u128)0x2360ED051FC65DA4ull << 64) | 0x4385DF649FCCF645ull;
+
+struct Pcg {
+    u128 state, inc;
+    bool has32 = false;
+    uint32_t hold = 0;
+    uint64_t next64()
+    {
+        state = state * PCG_MULT + inc;
+        const uint64_t hi = (uint64_t)(state >> 64), lo = (uint64_t)state;
+        const uint64_t v = hi ^ lo;
+        const unsigned rot = (unsigned)(hi >> 58);
+        return (v >> rot) | (v << ((64 - rot) & 63));
+    }
+    uint32_t next32()
+    {
+        if (has32) {
+            has32 = false;
+            return hold;
+        }
+        const uint64_t r = next64();
+        has32 = true;
+        hold = (uint32_t)(r >> 32);
+        return (uint32_t)r;
+    }
+    // uniform on [0, top], Lemire's method on 32-bit draws; top == 0 draws nothing
+    uint32_t bounded(uint32_t top)
+    {
+        if (top == 0) return 0;
+        if (top == 0xFFFFFFFFu) return next32();
+        const uint32_t span = top + 1;
+        uint64_t m = (uint64_t)next32() * span;
+        uint32_t low = (uint32_t)m;
+        if (low < span) {
+            const uint32_t thr = (uint32_t)((0xFFFFFFFFull - top) % span);
+            while (low < thr) {
+                m = (uint64_t)next32() * span;
+                low = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
+static void choice3_table(const uint64_t st[4], int64_t n, int32_t trials, int32_t *out)
+{
+    Pcg g;
+    g.state = ((u128)st[0] << 64) | st[1];
+    g.inc = ((u128)st[2] << 64) | st[3];
+    for (int32_t t = 0; t < trials; t++, out += 3) {
+        // Floyd's sampling of 3 out of n through a 4-slot open-addressed set ...
+        int64_t slot[4] = {-1, -1, -1, -1};
+        for (int k = 0; k < 3; k++) {
+            const int64_t j = n - 3 + k;
+            const int64_t v = g.bounded((uint32_t)j);
+            int at = (int)(v & 3);
+            while (slot[at] != -1 && slot[at] != v)
+                at = (at + 1) & 3;
+            if (slot[at] == -1) {
+                slot[at] = v;
+                out[k] = (int32_t)v;
+            } else {
+                at = (int)(j & 3);
+                while (slot[at] != -1)
+                    at = (at + 1) & 3;
+                slot[at] = j;
+                out[k] = (int32_t)j;
+            }
+        }
+        // ... followed by a shuffle of the three
+        for (int i = 2; i >= 1; i--)
+            std::swap(out[i], out[g.bounded((uint32_t)i)]);
+    }
+}
+
+}  // namespace pcfit
+
+using namespace pcfit;
+
+// ------------------------------------------------------------------ plumbing
+PCFIT_API int pcfit_version(void) { return 100; }
+PCFIT_API const char *pcfit_last_error(void) { return g_err; }
+
+PCFIT_API int pcfit_device_count(int *count)
+{
+    PCFIT_REQUIRE(count, "count is null");
+    PCFIT_HIP(hipGetDeviceCount(count));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_set_device(int device)
+{
+    PCFIT_HIP(hipSetDevice(device));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_malloc(void **ptr, size_t bytes)
+{
+    PCFIT_REQUIRE(ptr, "ptr is null");
+    PCFIT_HIP(hipMalloc(ptr, bytes ? bytes : 8));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_free(void *ptr)
+{
+    if (ptr) PCFIT_HIP(hipFree(ptr));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes) PCFIT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (bytes) PCFIT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_memset(void *dst, int value, size_t bytes, void *stream)
+{
+    if (bytes) PCFIT_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_stream_synchronize(void *stream)
+{
+    PCFIT_HIP(hipStreamSynchronize(as_stream(stream)));
+    return PCFIT_OK;
+}
+
+// ------------------------------------------------------------ sampling tables
+PCFIT_API int pcfit_seed_state(uint64_t seed, uint64_t state[4])
+{
+    PCFIT_REQUIRE(state, "state is null");
+    // SeedSequence: the seed as little-endian 32-bit words (at least one), mixed
+    // into a pool of four, from which eight output words are drawn
+    const uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int nent = ent[1] ? 2 : 1;
+    uint32_t pool[4], hc = 0x43b0d7e5u;
+    auto hashmix = [&](uint32_t v) {
+        v ^= hc;
+        hc *= 0x931e8875u;
+        v *= hc;
+        return v ^ (v >> 16);
+    };
+    auto mix = [](uint32_t a, uint32_t b) {
+        uint32_t r = 0xca01f9ddu * a - 0x4973f715u * b;
+        return r ^ (r >> 16);
+    };
+    for (int i = 0; i < 4; i++)
+        pool[i] = hashmix(i < nent ? ent[i] : 0u);
+    for (int s = 0; s < 4; s++)
+        for (int d = 0; d < 4; d++)
+            if (s != d)
+                pool[d] = mix(pool[d], hashmix(pool[s]));
+    uint32_t w[8], hb = 0x8b51f9ddu;
+    for (int i = 0; i < 8; i++) {
+        uint32_t v = pool[i & 3] ^ hb;
+        hb *= 0x58f38dedu;
+        v *= hb;
+        w[i] = v ^ (v >> 16);
+    }
+    uint64_t q[4];
+    for (int i = 0; i < 4; i++)
+        q[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    // PCG64 seeding: state = 0, inc = (seq << 1) | 1, step, add the seed, step
+    const u128 initstate = ((u128)q[0] << 64) | q[1], initseq = ((u128)q[2] << 64) | q[3];
+    const u128 inc = (initseq << 1) | 1;
+    u128 st = inc;                       // 0 * mult + inc
+    st += initstate;
+    st = st * PCG_MULT + inc;
+    state[0] = (uint64_t)(st >> 64);
+    state[1] = (uint64_t)st;
+    state[2] = (uint64_t)(inc >> 64);
+    state[3] = (uint64_t)inc;
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_choice3_table(const uint64_t state[4], int64_t n, int32_t trials, int32_t *out)
+{
+    PCFIT_REQUIRE(state && (out || trials == 0), "choice3: null pointer");
+    PCFIT_REQUIRE(n >= 3 && n <= 0xFFFFFFFFll, "choice3: n must be 3..2^32-1 (got %lld)", (long long)n);
+    PCFIT_REQUIRE(trials >= 0, "choice3: trials negative");
+    choice3_table(state, n, trials, out);
+    return PCFIT_OK;
+}
+
+// ------------------------------------------------- host-pointer entry points
+namespace pcfit {
+int launch_kasa(const double *, const double *, const int64_t *, int64_t, int64_t, double *, int32_t *, hipStream_t);
+}
+
+PCFIT_API int pcfit_kasa_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                               double *cxcyr, int32_t *status)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(cxcyr && (total == 0 || (x && y)), "kasa: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dout, dst;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dout.alloc(n_slices * 24));
+    PCFIT_TRY(dst.alloc(n_slices * 4));
+    PCFIT_TRY(launch_kasa(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
+                          dout.as<double>(), dst.as<int32_t>(), st));
+    PCFIT_TRY(dout.download(cxcyr, n_slices * 24, st));
+    PCFIT_TRY(dst.download(status, n_slices * 4, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_lm_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                             const double *init, double huber_delta, int32_t max_iter, double lm_lambda0,
+                             double tol_update, double tol_cost, double *out, int32_t *iters)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(init && out && (total == 0 || (x && y)), "lm: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dinit, dout, dit;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dinit.upload(init, n_slices * 24, st));
+    PCFIT_TRY(dout.alloc(n_slices * 24));
+    PCFIT_TRY(dit.alloc(n_slices * 8));
+    PCFIT_TRY(pcfit_lm_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
+                                 dinit.as<double>(), huber_delta, max_iter, lm_lambda0, tol_update, tol_cost,
+                                 dout.as<double>(), dit.as<int32_t>(), st));
+    PCFIT_TRY(dout.download(out, n_slices * 24, st));
+    PCFIT_TRY(dit.download(iters, n_slices * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_ransac_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                 double inlier_tol, int32_t trials, double min_inliers_frac, const double *r_range,
+                                 uint64_t seed, double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
+                                 int32_t *status)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(model && score && best_trial && status && (total == 0 || (x && y && mask)), "ransac: null pointer");
+    PCFIT_REQUIRE(trials >= 0, "ransac: trials negative");
+    // one sampling table per distinct slice population
+    uint64_t state[4];
+    PCFIT_TRY(pcfit_seed_state(seed, state));
+    std::map<int64_t, int32_t> table_id;
+    std::vector<int32_t> of_slice(n_slices, 0), tables;
+    for (int64_t s = 0; s < n_slices; s++) {
+        const int64_t n = offsets[s + 1] - offsets[s];
+        if (n < 3) continue;
+        auto it = table_id.find(n);
+        if (it == table_id.end()) {
+            it = table_id.emplace(n, (int32_t)table_id.size()).first;
+            tables.resize(tables.size() + (size_t)trials * 3);
+            PCFIT_TRY(pcfit_choice3_table(state, n, trials, tables.data() + (size_t)it->second * trials * 3));
+        }
+        of_slice[s] = it->second;
+    }
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dtab, dof, dmodel, dscore, dbest, dmask, dst, dws;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dtab.upload(tables.data(), tables.size() * 4, st));
+    PCFIT_TRY(dof.upload(of_slice.data(), n_slices * 4, st));
+    PCFIT_TRY(dmodel.alloc(n_slices * 24));
+    PCFIT_TRY(dscore.alloc(n_slices * 4));
+    PCFIT_TRY(dbest.alloc(n_slices * 4));
+    PCFIT_TRY(dmask.alloc(total));
+    PCFIT_TRY(dst.alloc(n_slices * 4));
+    PCFIT_TRY(dws.alloc(pcfit_ransac_workspace_bytes(n_slices)));
+    PCFIT_TRY(pcfit_ransac_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, inlier_tol,
+                                     trials, min_inliers_frac, r_range, dtab.as<int32_t>(), dof.as<int32_t>(),
+                                     dmodel.as<double>(), dscore.as<int32_t>(), dbest.as<int32_t>(),
+                                     dmask.as<uint8_t>(), dst.as<int32_t>(), dws.p, dws.bytes, st));
+    PCFIT_TRY(dmodel.download(model, n_slices * 24, st));
+    PCFIT_TRY(dscore.download(score, n_slices * 4, st));
+    PCFIT_TRY(dbest.download(best_trial, n_slices * 4, st));
+    PCFIT_TRY(dmask.download(mask, total, st));
+    PCFIT_TRY(dst.download(status, n_slices * 4, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_residuals_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                    const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
+                                    const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(cxcyr && rmax_rmin && argmax_argmin && (total == 0 || (x && y)), "residuals: null pointer");
+    PCFIT_REQUIRE(n_bins >= 0 && (n_bins == 0 || (edges && hist)), "residuals: bad histogram arguments");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dfit, dth, ddr, drad, dedge, dhist, drm, dam;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
+    if (theta) PCFIT_TRY(dth.alloc(total * 8));
+    if (dr) PCFIT_TRY(ddr.alloc(total * 8));
+    if (radius) PCFIT_TRY(drad.alloc(total * 8));
+    if (n_bins) {
+        PCFIT_TRY(dedge.upload(edges, (size_t)(n_bins + 1) * 8, st));
+        PCFIT_TRY(dhist.alloc((size_t)n_slices * n_bins * 8));
+    }
+    PCFIT_TRY(drm.alloc(n_slices * 16));
+    PCFIT_TRY(dam.alloc(n_slices * 16));
+    PCFIT_TRY(pcfit_residuals_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
+                                        dfit.as<double>(), dth.as<double>(), ddr.as<double>(), drad.as<double>(), n_bins,
+                                        dedge.as<double>(), dhist.as<int64_t>(), drm.as<double>(), dam.as<int64_t>(),
+                                        st));
+    if (theta) PCFIT_TRY(dth.download(theta, total * 8, st));
+    if (dr) PCFIT_TRY(ddr.download(dr, total * 8, st));
+    if (radius) PCFIT_TRY(drad.download(radius, total * 8, st));
+    if (n_bins) PCFIT_TRY(dhist.download(hist, (size_t)n_slices * n_bins * 8, st));
+    PCFIT_TRY(drm.download(rmax_rmin, n_slices * 16, st));
+    PCFIT_TRY(dam.download(argmax_argmin, n_slices * 16, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_angle_max_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                    const double *cxcyr, int32_t bins, int64_t *sel)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(cxcyr && sel && (total == 0 || (x && y)), "angle_max: null pointer");
+    PCFIT_REQUIRE(max_len < 0xffffffffll, "angle_max: slice longer than 2^32-2 points");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dfit, dsel;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
+    PCFIT_TRY(dsel.alloc((size_t)n_slices * (bins > 0 ? bins : 1) * 8));
+    PCFIT_TRY(pcfit_angle_max_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
+                                        dfit.as<double>(), bins, dsel.as<int64_t>(), st));
+    PCFIT_TRY(dsel.download(sel, (size_t)n_slices * bins * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}

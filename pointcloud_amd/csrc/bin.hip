@@ -1,0 +1,451 @@
+// Slice binning: scatter the (x, y) of every point into slice-contiguous arrays,
+// keeping the original order inside a slice (analyzer.py:49-52 takes
+// points[mask] per window).  A stable counting sort in three steps, gfx950:
+//
+//   count    one wave per contiguous chunk of the input builds the chunk's
+//            per-window histogram in LDS and stores it as a row of a
+//            chunks x windows matrix;
+//   scan     column-wise exclusive prefix over the chunk rows (segmented in
+//            three small kernels) plus the prefix over windows = CSR offsets;
+//   scatter  the same wave walks its chunk again, 64 points a step.  Lanes
+//            holding the same window find each other with ballots over the key
+//            bits, so a lane's rank among its peers and the peer count are bit
+//            counts; one LDS cursor per window (private to the wave, seeded from
+//            the scan) gives the output position.  No atomics, no inter-wave
+//            ordering: stable and deterministic by construction.
+//
+// Windows are closed intervals that may share an edge, so a point can belong
+// to two consecutive windows (both get a copy) or to none.  Membership is
+// decided by the caller's z_lo / z_hi arrays, compared exactly; the uniform
+// spacing is used only to find the candidate window and to skip the array
+// look-ups for points that are clearly interior.
+// HBM traffic: 24 B/point read in count, 24 B read + 16 B (+8 B perm) written
+// in scatter.
+#include <algorithm>
+#include <vector>
+
+#include "pcfit_internal.h"
+
+namespace pcfit {
+
+constexpr int BIN_SEG = 64;            // chunk rows per scan segment
+constexpr int64_t BIN_MAX_SLICES = 16384;
+constexpr double BIN_EDGE_EPS = 1e-6;  // in units of the window step
+
+struct BinGeom {
+    double lo0, inv_step, rel_width;   // rel_width = (z_hi[0]-z_lo[0]) / step
+    int64_t S;
+};
+
+// windows containing z: k1 (or -1) and, if a second one, k1 + 1 (has2)
+__device__ __forceinline__ void windows_of(double z, const BinGeom &g, const double *__restrict__ z_lo,
+                                           const double *__restrict__ z_hi, int32_t &k1, bool &has2)
+{
+    k1 = -1;
+    has2 = false;
+    if (!(z == z))
+        return;
+    const double t = (z - g.lo0) * g.inv_step;
+    if (!(t > -2.0) || !(t < (double)g.S + 2.0))
+        return;
+    const double ft = floor(t);
+    const int64_t k0 = (int64_t)ft;
+    const double frac = t - ft;
+    if (frac > BIN_EDGE_EPS && frac < g.rel_width - BIN_EDGE_EPS) {
+        if (k0 >= 0 && k0 < g.S)
+            k1 = (int32_t)k0;
+        return;
+    }
+    if (frac > g.rel_width + BIN_EDGE_EPS && frac < 1.0 - BIN_EDGE_EPS)
+        return;                                             // in the gap between two windows
+    // near an edge: the arrays decide, exactly as z >= lo && z <= hi
+#pragma unroll
+    for (int d = -1; d <= 1; d++) {
+        const int64_t k = k0 + d;
+        if (k < 0 || k >= g.S)
+            continue;
+        if (z >= z_lo[k] && z <= z_hi[k]) {
+            if (k1 < 0)
+                k1 = (int32_t)k;
+            else
+                has2 = true;                                // windows are consecutive: this is k1 + 1
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void bin_count_kernel(const double *__restrict__ xyz, int64_t n, int64_t chunk_len,
+                                                      const double *__restrict__ z_lo,
+                                                      const double *__restrict__ z_hi, BinGeom g,
+                                                      uint32_t *__restrict__ counts)
+{
+    extern __shared__ uint32_t lhist[];
+    const int64_t c = blockIdx.x;
+    for (int64_t s = threadIdx.x; s < g.S; s += 64)
+        lhist[s] = 0;
+    __syncthreads();
+    const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
+    for (int64_t i = begin + threadIdx.x; i < end; i += 64) {
+        int32_t k1;
+        bool has2;
+        windows_of(xyz[3 * i + 2], g, z_lo, z_hi, k1, has2);
+        if (k1 >= 0) {
+            atomicAdd(&lhist[k1], 1u);
+            if (has2)
+                atomicAdd(&lhist[k1 + 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (int64_t s = threadIdx.x; s < g.S; s += 64)
+        counts[c * g.S + s] = lhist[s];
+}
+
+// segment sums: segsum[g][s] = sum of counts rows of segment g
+__global__ void bin_segsum_kernel(const uint32_t *__restrict__ counts, int64_t chunks, int64_t S,
+                                  int64_t *__restrict__ segsum)
+{
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t seg = blockIdx.y;
+    if (s >= S)
+        return;
+    const int64_t c0 = seg * BIN_SEG, c1 = min(chunks, c0 + BIN_SEG);
+    int64_t acc = 0;
+    for (int64_t c = c0; c < c1; c++)
+        acc += counts[c * S + s];
+    segsum[seg * S + s] = acc;
+}
+
+// per window: exclusive prefix of the segment sums (in place) and the total
+__global__ void bin_segscan_kernel(int64_t *__restrict__ segsum, int64_t segs, int64_t S,
+                                   int64_t *__restrict__ totals)
+{
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= S)
+        return;
+    int64_t run = 0;
+    for (int64_t g = 0; g < segs; g++) {
+        const int64_t t = segsum[g * S + s];
+        segsum[g * S + s] = run;
+        run += t;
+    }
+    totals[s] = run;
+}
+
+// offsets[0..S] = exclusive prefix of totals; one workgroup, serial over tiles of 1024
+__global__ __launch_bounds__(1024) void bin_offsets_kernel(const int64_t *__restrict__ totals, int64_t S,
+                                                          int64_t *__restrict__ offsets)
+{
+    __shared__ int64_t part[1024];
+    __shared__ int64_t carry;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < S; base += 1024) {
+        const int64_t s = base + threadIdx.x;
+        const int64_t v = s < S ? totals[s] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int64_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int64_t incl = part[threadIdx.x];
+        if (s < S)
+            offsets[s] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        offsets[S] = carry;
+}
+
+// counts[c][s] <- number of members of window s in the chunks of c's segment before c
+__global__ void bin_rowscan_kernel(uint32_t *__restrict__ counts, int64_t chunks, int64_t S)
+{
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t seg = blockIdx.y;
+    if (s >= S)
+        return;
+    const int64_t c0 = seg * BIN_SEG, c1 = min(chunks, c0 + BIN_SEG);
+    uint32_t run = 0;
+    for (int64_t c = c0; c < c1; c++) {
+        const uint32_t t = counts[c * S + s];
+        counts[c * S + s] = run;
+        run += t;
+    }
+}
+
+// lanes whose key equals this lane's query: ballots over the key bits
+__device__ __forceinline__ uint64_t match_lanes(const uint64_t *bit_ballot, int nbits, uint32_t query)
+{
+    uint64_t m = ~0ull;
+    for (int b = 0; b < nbits; b++)
+        m &= ((query >> b) & 1u) ? bit_ballot[b] : ~bit_ballot[b];
+    return m;
+}
+
+__global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restrict__ xyz, int64_t n, int64_t chunk_len,
+                                                        const double *__restrict__ z_lo,
+                                                        const double *__restrict__ z_hi, BinGeom g, int nbits,
+                                                        const uint32_t *__restrict__ counts,
+                                                        const int64_t *__restrict__ segbase,
+                                                        const int64_t *__restrict__ offsets,
+                                                        double *__restrict__ x_out, double *__restrict__ y_out,
+                                                        int64_t *__restrict__ perm)
+{
+    extern __shared__ int64_t cursor[];
+    const int64_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t below = (1ull << lane) - 1ull;
+    for (int64_t s = lane; s < g.S; s += 64)
+        cursor[s] = offsets[s] + segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s];
+    __syncthreads();
+    const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
+    for (int64_t base = begin; base < end; base += 64) {
+        const int64_t i = base + lane;
+        int32_t k1 = -1;
+        bool has2 = false;
+        double px = 0.0, py = 0.0;
+        if (i < end) {
+            px = xyz[3 * i];
+            py = xyz[3 * i + 1];
+            windows_of(xyz[3 * i + 2], g, z_lo, z_hi, k1, has2);
+        }
+        // key 0 = no window, key k+1 = window k
+        const uint32_t key = (uint32_t)(k1 + 1);
+        uint64_t bit_ballot[16];
+        for (int b = 0; b < nbits; b++)
+            bit_ballot[b] = __ballot((key >> b) & 1u);
+        const uint64_t twice = __ballot(has2);
+        uint64_t same = match_lanes(bit_ballot, nbits, key);
+        if (twice == 0ull) {
+            if (k1 >= 0) {
+                const int rank = __popcll(same & below), cnt = __popcll(same);
+                const int64_t at = cursor[k1];
+                if (rank == cnt - 1)
+                    cursor[k1] = at + cnt;
+                x_out[at + rank] = px;
+                y_out[at + rank] = py;
+                if (perm) perm[at + rank] = i;
+            }
+        } else {
+            // window k receives lanes with key1 == k and lanes with key1 == k-1 that lie in two windows
+            const uint64_t from_prev = match_lanes(bit_ballot, nbits, key - 1u) & twice;   // key-1 = window k1-1
+            const uint64_t to_next = match_lanes(bit_ballot, nbits, key + 1u);            // lanes in window k1+1
+            int64_t at1 = 0, at2 = 0;
+            int rank1 = 0, cnt1 = 0, rank2 = 0, cnt2 = 0;
+            if (k1 >= 0) {
+                const uint64_t grp1 = same | (key >= 2u ? from_prev : 0ull);
+                rank1 = __popcll(grp1 & below);
+                cnt1 = __popcll(grp1);
+                at1 = cursor[k1];
+                if (has2) {
+                    const uint64_t grp2 = to_next | (same & twice);
+                    rank2 = __popcll(grp2 & below);
+                    cnt2 = __popcll(grp2);
+                    at2 = cursor[k1 + 1];
+                }
+            }
+            // all reads of the cursors precede the writes (one wave, LDS ops in order)
+            if (k1 >= 0) {
+                if (rank1 == cnt1 - 1)
+                    cursor[k1] = at1 + cnt1;
+                if (has2 && rank2 == cnt2 - 1)
+                    cursor[k1 + 1] = at2 + cnt2;
+                x_out[at1 + rank1] = px;
+                y_out[at1 + rank1] = py;
+                if (perm) perm[at1 + rank1] = i;
+                if (has2) {
+                    x_out[at2 + rank2] = px;
+                    y_out[at2 + rank2] = py;
+                    if (perm) perm[at2 + rank2] = i;
+                }
+            }
+        }
+    }
+}
+
+struct BinPlan {
+    int64_t chunks, chunk_len, segs;
+    size_t counts_off, segsum_off, totals_off, bytes;
+};
+
+static BinPlan bin_plan(int64_t n, int64_t S)
+{
+    BinPlan p;
+    const int64_t Sg = std::max<int64_t>(S, 1);
+    int64_t chunks = std::max<int64_t>(1, (n + 4095) / 4096);
+    chunks = std::min<int64_t>(chunks, std::min<int64_t>(2048, std::max<int64_t>(1, (16ll << 20) / Sg)));
+    int64_t len = (n + chunks - 1) / std::max<int64_t>(chunks, 1);
+    len = std::max<int64_t>(64, (len + 63) / 64 * 64);
+    chunks = std::max<int64_t>(1, (n + len - 1) / len);
+    p.chunks = chunks;
+    p.chunk_len = len;
+    p.segs = (chunks + BIN_SEG - 1) / BIN_SEG;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    p.counts_off = 0;
+    p.segsum_off = up((size_t)chunks * Sg * 4);
+    p.totals_off = p.segsum_off + up((size_t)p.segs * Sg * 8);
+    p.bytes = p.totals_off + up((size_t)Sg * 8);
+    return p;
+}
+
+static int bin_geom(const double *z_lo_host3, int64_t S, BinGeom &g)
+{
+    // z_lo_host3 = {z_lo[0], z_hi[0], z_lo[S-1]}
+    g.S = S;
+    g.lo0 = z_lo_host3[0];
+    const double width = z_lo_host3[1] - z_lo_host3[0];
+    const double step = S > 1 ? (z_lo_host3[2] - z_lo_host3[0]) / (double)(S - 1) : (width > 0 ? width : 1.0);
+    PCFIT_REQUIRE(step > 0 && width >= 0 && std::isfinite(step) && std::isfinite(width),
+                  "bin: windows must be ascending with finite bounds");
+    PCFIT_REQUIRE(width <= step * (1.0 + 1e-7), "bin: windows overlap by more than a shared edge");
+    g.inv_step = 1.0 / step;
+    g.rel_width = width / step;
+    return PCFIT_OK;
+}
+
+}  // namespace pcfit
+
+using namespace pcfit;
+
+PCFIT_API size_t pcfit_bin_workspace_bytes(int64_t n_points, int64_t n_slices)
+{
+    return bin_plan(std::max<int64_t>(n_points, 0), n_slices).bytes;
+}
+
+PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                  int64_t n_slices, const double *window_geom, int64_t *offsets, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
+    if (n_slices > BIN_MAX_SLICES) {
+        set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)n_slices);
+        return PCFIT_ERR_UNSUPPORTED;
+    }
+    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && (xyz || n_points == 0), "bin: null pointer");
+    const BinPlan p = bin_plan(n_points, n_slices);
+    if (!workspace || workspace_bytes < p.bytes) {
+        set_error("bin: workspace of %zu bytes needed", p.bytes);
+        return PCFIT_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    BinGeom g;
+    int rc = bin_geom(window_geom, n_slices, g);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(workspace);
+    uint32_t *counts = reinterpret_cast<uint32_t *>(ws + p.counts_off);
+    int64_t *segsum = reinterpret_cast<int64_t *>(ws + p.segsum_off);
+    int64_t *totals = reinterpret_cast<int64_t *>(ws + p.totals_off);
+    const int64_t S = n_slices;
+    bin_count_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(xyz, n_points, p.chunk_len, z_lo, z_hi,
+                                                                              g, counts);
+    PCFIT_LAUNCH_CHECK();
+    const dim3 cols((unsigned)((S + 255) / 256), (unsigned)p.segs);
+    bin_segsum_kernel<<<cols, dim3(256), 0, st>>>(counts, p.chunks, S, segsum);
+    PCFIT_LAUNCH_CHECK();
+    bin_segscan_kernel<<<dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st>>>(segsum, p.segs, S, totals);
+    PCFIT_LAUNCH_CHECK();
+    bin_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(totals, S, offsets);
+    PCFIT_LAUNCH_CHECK();
+    bin_rowscan_kernel<<<cols, dim3(256), 0, st>>>(counts, p.chunks, S);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                    int64_t n_slices, const double *window_geom, const int64_t *offsets,
+                                    double *x_out, double *y_out, int64_t *perm, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1 && n_slices <= BIN_MAX_SLICES, "bin: bad sizes");
+    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && x_out && y_out && (xyz || n_points == 0),
+                  "bin: null pointer");
+    const BinPlan p = bin_plan(n_points, n_slices);
+    if (!workspace || workspace_bytes < p.bytes) {
+        set_error("bin: workspace of %zu bytes needed (the one pcfit_bin_count_dev filled)", p.bytes);
+        return PCFIT_ERR_WORKSPACE;
+    }
+    hipStream_t st = as_stream(stream);
+    BinGeom g;
+    int rc = bin_geom(window_geom, n_slices, g);
+    if (rc) return rc;
+    char *ws = static_cast<char *>(workspace);
+    const uint32_t *counts = reinterpret_cast<const uint32_t *>(ws + p.counts_off);
+    const int64_t *segsum = reinterpret_cast<const int64_t *>(ws + p.segsum_off);
+    int nbits = 1;
+    while ((1ll << nbits) < n_slices + 2)
+        nbits++;
+    bin_scatter_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 8, st>>>(
+        xyz, n_points, p.chunk_len, z_lo, z_hi, g, nbits, counts, segsum, offsets, x_out, y_out, perm);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                               int64_t n_slices, int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
+                               int64_t capacity, int64_t *total)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
+    PCFIT_REQUIRE(z_lo && z_hi && offsets && total && (xyz || n_points == 0), "bin: null pointer");
+    // the windows must be what analyzer.py:240-243 builds: ascending, near-uniform
+    const double step = n_slices > 1 ? (z_lo[n_slices - 1] - z_lo[0]) / (double)(n_slices - 1) : 1.0;
+    const double width = z_hi[0] - z_lo[0];
+    for (int64_t s = 0; s < n_slices; s++) {
+        const double want = z_lo[0] + (double)s * step;
+        PCFIT_REQUIRE(fabs(z_lo[s] - want) <= 1e-7 * step && fabs((z_hi[s] - z_lo[s]) - width) <= 1e-7 * step,
+                      "bin: windows are not uniformly spaced (window %lld)", (long long)s);
+    }
+    const double geom[3] = {z_lo[0], z_hi[0], z_lo[n_slices - 1]};
+    hipStream_t st = nullptr;
+    void *d_xyz = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_off = nullptr, *d_ws = nullptr, *d_x = nullptr,
+         *d_y = nullptr, *d_perm = nullptr;
+    int rc = PCFIT_OK;
+    const size_t ws_bytes = pcfit_bin_workspace_bytes(n_points, n_slices);
+    auto cleanup = [&]() {
+        for (void *p : {d_xyz, d_lo, d_hi, d_off, d_ws, d_x, d_y, d_perm})
+            if (p) (void)hipFree(p);
+    };
+#define BIN_TRY(expr)                 \
+    do {                              \
+        rc = (expr);                  \
+        if (rc != PCFIT_OK) {         \
+            cleanup();                \
+            return rc;                \
+        }                             \
+    } while (0)
+    BIN_TRY(pcfit_malloc(&d_xyz, (size_t)n_points * 24));
+    BIN_TRY(pcfit_malloc(&d_lo, (size_t)n_slices * 8));
+    BIN_TRY(pcfit_malloc(&d_hi, (size_t)n_slices * 8));
+    BIN_TRY(pcfit_malloc(&d_off, (size_t)(n_slices + 1) * 8));
+    BIN_TRY(pcfit_malloc(&d_ws, ws_bytes));
+    BIN_TRY(pcfit_memcpy_h2d(d_xyz, xyz, (size_t)n_points * 24, st));
+    BIN_TRY(pcfit_memcpy_h2d(d_lo, z_lo, (size_t)n_slices * 8, st));
+    BIN_TRY(pcfit_memcpy_h2d(d_hi, z_hi, (size_t)n_slices * 8, st));
+    BIN_TRY(pcfit_bin_count_dev((const double *)d_xyz, n_points, (const double *)d_lo, (const double *)d_hi, n_slices,
+                                geom, (int64_t *)d_off, d_ws, ws_bytes, st));
+    BIN_TRY(pcfit_memcpy_d2h(offsets, d_off, (size_t)(n_slices + 1) * 8, st));
+    BIN_TRY(pcfit_stream_synchronize(st));
+    *total = offsets[n_slices];
+    if (*total > capacity || ((x_out == nullptr || y_out == nullptr) && *total > 0)) {
+        cleanup();
+        set_error("bin: outputs hold %lld points, %lld needed", (long long)capacity, (long long)*total);
+        return PCFIT_ERR_INVALID;
+    }
+    BIN_TRY(pcfit_malloc(&d_x, (size_t)*total * 8));
+    BIN_TRY(pcfit_malloc(&d_y, (size_t)*total * 8));
+    if (perm) BIN_TRY(pcfit_malloc(&d_perm, (size_t)*total * 8));
+    BIN_TRY(pcfit_bin_scatter_dev((const double *)d_xyz, n_points, (const double *)d_lo, (const double *)d_hi,
+                                  n_slices, geom, (const int64_t *)d_off, (double *)d_x, (double *)d_y, (int64_t *)d_perm,
+                                  d_ws, ws_bytes, st));
+    BIN_TRY(pcfit_memcpy_d2h(x_out, d_x, (size_t)*total * 8, st));
+    BIN_TRY(pcfit_memcpy_d2h(y_out, d_y, (size_t)*total * 8, st));
+    if (perm) BIN_TRY(pcfit_memcpy_d2h(perm, d_perm, (size_t)*total * 8, st));
+    BIN_TRY(pcfit_stream_synchronize(st));
+#undef BIN_TRY
+    cleanup();
+    return PCFIT_OK;
+}

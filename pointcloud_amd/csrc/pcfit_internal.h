@@ -1,0 +1,182 @@
+// Internal helpers shared by the kernel files of libpcfit_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "pcfit.h"
+
+#define PCFIT_API extern "C" __attribute__((visibility("default")))
+
+namespace pcfit {
+
+void set_error(const char *fmt, ...);
+
+#define PCFIT_HIP(call)                                                                       \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            pcfit::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return PCFIT_ERR_HIP;                                                             \
+        }                                                                                     \
+    } while (0)
+
+#define PCFIT_REQUIRE(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            pcfit::set_error(__VA_ARGS__);       \
+            return PCFIT_ERR_INVALID;            \
+        }                                        \
+    } while (0)
+
+// kernel launches are asynchronous: this catches bad launch configurations only
+#define PCFIT_LAUNCH_CHECK() PCFIT_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Device buffer that frees itself: the host-pointer entry points own all the
+// device memory they touch for the duration of one call.
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n)
+    {
+        if (p && n <= bytes) return PCFIT_OK;          // reuse
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        PCFIT_HIP(hipMalloc(&p, n ? n : 8));
+        return PCFIT_OK;
+    }
+    int upload(const void *src, size_t n, hipStream_t st)
+    {
+        int rc = alloc(n);
+        if (rc) return rc;
+        if (n) PCFIT_HIP(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, st));
+        return PCFIT_OK;
+    }
+    int download(void *dst, size_t n, hipStream_t st) const
+    {
+        if (n && dst) PCFIT_HIP(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, st));
+        return PCFIT_OK;
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+#define PCFIT_TRY(expr)          \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != PCFIT_OK)     \
+            return rc_;          \
+    } while (0)
+
+inline int check_offsets(const int64_t *offsets, int64_t S, int64_t *total, int64_t *max_len)
+{
+    PCFIT_REQUIRE(S >= 0, "n_slices negative");
+    PCFIT_REQUIRE(offsets != nullptr, "offsets is null");
+    int64_t mx = 0;
+    for (int64_t s = 0; s < S; s++) {
+        PCFIT_REQUIRE(offsets[s + 1] >= offsets[s], "offsets must be non-decreasing (slice %lld)", (long long)s);
+        mx = std::max(mx, offsets[s + 1] - offsets[s]);
+    }
+    PCFIT_REQUIRE(offsets[0] >= 0, "offsets[0] negative");
+    *total = offsets[S];
+    *max_len = mx;
+    return PCFIT_OK;
+}
+
+
+constexpr int WAVE = 64;
+constexpr double TWO_PI = 6.283185307179586476925286766559;
+
+// ---------------------------------------------------------------- device side
+// Butterfly sum over the 64 lanes of a wave: every lane ends with the same
+// value, the order of additions is fixed (bitwise reproducible).
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, WAVE);
+    return v;
+}
+
+// Sum K values per thread over a whole workgroup (blockDim.x a multiple of 64,
+// at most 1024).  All threads receive the K totals.  scratch: K * 16 doubles
+// of LDS.  Fixed order: lanes by butterfly, then waves 0,1,2,...
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        v[k] = wave_sum(v[k]);
+    if (nw == 1)
+        return;
+    __syncthreads();                       // scratch may still be read from a previous call
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            scratch[k * 16 + wave] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = scratch[k * 16];
+        for (int w = 1; w < nw; w++)
+            s += scratch[k * 16 + w];
+        v[k] = s;
+    }
+}
+
+// (theta, r) as the reference forms them: theta = (atan2(dy,dx) + 2pi) mod 2pi
+__device__ __forceinline__ double wrap_angle(double dy, double dx)
+{
+    return fmod(atan2(dy, dx) + TWO_PI, TWO_PI);
+}
+
+// hypot(x, y) rounded to nearest: sqrt of the double-double sum of squares, then
+// one Newton correction with the residual taken exactly.  No range scaling:
+// meant for |x|, |y| within [1e-140, 1e140].
+__device__ __forceinline__ double cr_hypot(double x, double y)
+{
+    const double p1 = x * x, e1 = fma(x, x, -p1);
+    const double p2 = y * y, e2 = fma(y, y, -p2);
+    const double s = p1 + p2;
+    const double bv = s - p1;
+    const double es = (p1 - (s - bv)) + (p2 - bv);
+    const double tail = es + (e1 + e2);
+    const double r = sqrt(s);
+    if (!(r > 0.0) || !isfinite(r))
+        return r;
+    const double rr = r * r, er = fma(r, r, -rr);
+    const double resid = ((s - rr) - er) + tail;
+    return r + resid / (2.0 * r);
+}
+
+__device__ __forceinline__ double next_up(double v) { return __longlong_as_double(__double_as_longlong(v) + 1); }
+__device__ __forceinline__ double next_down(double v) { return __longlong_as_double(__double_as_longlong(v) - 1); }
+
+// 2x2 solve exactly as LAPACK dgesv evaluates it on the build host (partial
+// pivoting, reciprocal-scaled multiplier, fused multiply-adds in the two
+// triangular solves).  Rows (a b | c), (d e | f); returns the pivot product.
+__device__ __forceinline__ double solve2x2(double a, double b, double c, double d, double e, double f, double &x1,
+                                           double &x2)
+{
+    if (fabs(d) > fabs(a)) {
+        double t;
+        t = a; a = d; d = t;
+        t = b; b = e; e = t;
+        t = c; c = f; f = t;
+    }
+    const double l = d * (1.0 / a);
+    const double u22 = e - l * b;
+    const double y2 = fma(-l, c, f);
+    x2 = y2 / u22;
+    x1 = fma(-b, x2, c) / a;
+    return a * u22;
+}
+
+}  // namespace pcfit

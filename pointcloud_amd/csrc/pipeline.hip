@@ -1,0 +1,556 @@
+// Ovality / k=2 Fourier amplitude (boundary.py:56-90), the small glue kernels
+// of the hybrid fit (candidate gather, inlier compaction) and the host driver
+// that chains unique -> hull -> RANSAC -> Kasa -> LM -> metrics for a batch of
+// slices (fit_circle_hybrid_at_z, circle_fitting.py:146-232, followed by the
+// per-slice metrics of analyzer.py:83-95).
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "pcfit_internal.h"
+
+namespace pcfit {
+
+constexpr int OV_BLOCK = 256;
+constexpr int OV_CAP = 8192;
+
+// One workgroup per slice.  Dynamic LDS: theta[cap], dev[cap] doubles, id[cap] uint16.
+__global__ __launch_bounds__(OV_BLOCK) void ovality_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                          const int64_t *__restrict__ offsets,
+                                                          const double *__restrict__ cxcyr, int cap,
+                                                          double *__restrict__ scal, double *__restrict__ dev_uniform,
+                                                          int64_t grid_len)
+{
+    extern __shared__ double lds_dyn[];
+    __shared__ double red[4 * 16];
+    double *th = lds_dyn, *dv = lds_dyn + cap;
+    uint16_t *id = reinterpret_cast<uint16_t *>(lds_dyn + 2 * cap);
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], n = offsets[s + 1] - off;
+    const double cx = cxcyr[3 * s], cy = cxcyr[3 * s + 1], R = cxcyr[3 * s + 2];
+    const int tid = threadIdx.x;
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    if (n < 1 || n > cap || !(cx == cx) || !(cy == cy) || !(R == R)) {
+        if (tid < 5)
+            scal[5 * s + tid] = qnan;
+        return;
+    }
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double rmax = -inf, rmin = inf;
+    for (int64_t i = tid; i < n; i += OV_BLOCK) {
+        const double dx = x[off + i] - cx, dy = y[off + i] - cy;
+        const double r = cr_hypot(dx, dy);
+        th[i] = wrap_angle(dy, dx);
+        dv[i] = r - R;
+        id[i] = (uint16_t)i;
+        rmax = fmax(rmax, r);
+        rmin = fmin(rmin, r);
+    }
+    // max / min over the workgroup (order independent)
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        rmax = fmax(rmax, __shfl_xor(rmax, m, WAVE));
+        rmin = fmin(rmin, __shfl_xor(rmin, m, WAVE));
+    }
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = rmax;
+        red[16 + (tid >> 6)] = rmin;
+    }
+    __syncthreads();
+    for (int w = 0; w < OV_BLOCK / WAVE; w++) {
+        rmax = fmax(rmax, red[w]);
+        rmin = fmin(rmin, red[16 + w]);
+    }
+    // argsort by theta (ties by index): ascending-only bitonic network, virtual +inf padding
+    int64_t P = 1;
+    while (P < n) P <<= 1;
+    for (int64_t k = 2; k <= P; k <<= 1) {
+        for (int64_t d = k >> 1; d >= 1; d >>= 1) {
+            const bool flip = d == (k >> 1);
+            for (int64_t q = tid; q < (P >> 1); q += OV_BLOCK) {
+                int64_t i, j;
+                if (flip) {
+                    const int64_t blk = q / d, o = q % d;
+                    i = blk * k + o;
+                    j = blk * k + (k - 1 - o);
+                } else {
+                    i = 2 * d * (q / d) + (q % d);
+                    j = i + d;
+                }
+                if (j < n) {
+                    const double a = th[i], b = th[j];
+                    const uint16_t ia = id[i], ib = id[j];
+                    if (b < a || (b == a && ib < ia)) {
+                        const double da = dv[i], db = dv[j];
+                        th[i] = b; th[j] = a;
+                        dv[i] = db; dv[j] = da;
+                        id[i] = ib; id[j] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // periodic linear interpolation on K = max(1024, n) uniform angles + the k=2 DFT bin
+    const int64_t K = n > 1024 ? n : 1024;
+    const double step = TWO_PI / (double)K;
+    double acc[2] = {0.0, 0.0};
+    for (int64_t k = tid; k < K; k += OV_BLOCK) {
+        const double t = (double)k * step;
+        // largest j in [-1, n-1] with xp[j] <= t, xp[-1] = th[n-1] - 2pi
+        int64_t lo = -1, hi = n - 1;
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo + 1) / 2;
+            if (th[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int64_t j = lo;
+        const double xj = j < 0 ? th[n - 1] - TWO_PI : th[j];
+        const double fj = j < 0 ? dv[n - 1] : dv[j];
+        double v;
+        if (xj == t) {
+            v = fj;
+        } else {
+            const double xn = j + 1 < n ? th[j + 1] : th[0] + TWO_PI;
+            const double fn = j + 1 < n ? dv[j + 1] : dv[0];
+            const double slope = (fn - fj) / (xn - xj);
+            v = slope * (t - xj) + fj;
+        }
+        if (dev_uniform)
+            dev_uniform[s * grid_len + k] = v;
+        const double ang = 2.0 * TWO_PI * (double)k / (double)K;
+        acc[0] += v * cos(ang);
+        acc[1] -= v * sin(ang);
+    }
+    block_sum<2>(acc, red + 32);
+    if (tid == 0) {
+        scal[5 * s] = rmax;
+        scal[5 * s + 1] = rmin;
+        scal[5 * s + 2] = rmax - rmin;
+        scal[5 * s + 3] = R > 0 ? 100.0 * (rmax - rmin) / R : qnan;
+        scal[5 * s + 4] = sqrt(acc[0] * acc[0] + acc[1] * acc[1]) / ((double)K / 2.0);
+    }
+}
+
+// circle_fitting.py:14-19 for m points at px, py (global memory), evaluated by a
+// 256-thread workgroup; the same value in every thread.  red: 48 doubles of LDS.
+__device__ bool has_2d_variation_block(const double *__restrict__ px, const double *__restrict__ py, int64_t m,
+                                       double eps, double *red)
+{
+    if (m < 3)
+        return false;
+    const int tid = threadIdx.x;
+    double s1[2] = {0.0, 0.0};
+    for (int64_t i = tid; i < m; i += 256) {
+        s1[0] += px[i];
+        s1[1] += py[i];
+    }
+    block_sum<2>(s1, red);
+    const double mx = s1[0] / (double)m, my = s1[1] / (double)m;
+    double sc[3] = {0.0, 0.0, 0.0};
+    for (int64_t i = tid; i < m; i += 256) {
+        const double u = px[i] - mx, v = py[i] - my;
+        sc[0] += u * u;
+        sc[1] += u * v;
+        sc[2] += v * v;
+    }
+    block_sum<3>(sc, red);
+    const double phi = 0.5 * atan2(2 * sc[1], sc[0] - sc[2]);
+    const double c = cos(phi), sn = sin(phi);
+    double pr[2] = {0.0, 0.0};
+    for (int64_t i = tid; i < m; i += 256) {
+        const double u = px[i] - mx, v = py[i] - my;
+        const double a = c * u + sn * v, b = c * v - sn * u;
+        pr[0] += a * a;
+        pr[1] += b * b;
+    }
+    block_sum<2>(pr, red);
+    double s0 = sqrt(pr[0]), s1v = sqrt(pr[1]);
+    if (s1v > s0) {
+        const double t = s0;
+        s0 = s1v;
+        s1v = t;
+    }
+    return s1v > eps * (s0 + eps);
+}
+
+// candidates of a slice: its hull vertices (in hull order) or all its distinct
+// points; also the second rank check of circle_fitting.py:200 on them.
+__global__ __launch_bounds__(256) void gather_candidates_kernel(
+    const double *__restrict__ ux, const double *__restrict__ uy, const int64_t *__restrict__ offsets,
+    const int64_t *__restrict__ hull_idx, const int64_t *__restrict__ cand_offsets, int use_hull,
+    double *__restrict__ cand_x, double *__restrict__ cand_y, int32_t *__restrict__ status)
+{
+    __shared__ double red[3 * 16];
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], co = cand_offsets[s], m = cand_offsets[s + 1] - co;
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < m; i += 256) {
+        const int64_t src = use_hull ? hull_idx[off + i] : i;
+        cand_x[co + i] = ux[off + src];
+        cand_y[co + i] = uy[off + src];
+    }
+    if (m < 3)
+        return;
+    __syncthreads();
+    const bool ok = has_2d_variation_block(cand_x + co, cand_y + co, m, 1e-12, red);
+    if (tid == 0 && !ok)
+        status[s] = PCFIT_ST_RANK;
+}
+
+__global__ __launch_bounds__(256) void rank_kernel(const double *__restrict__ x, const double *__restrict__ y,
+                                                  const int64_t *__restrict__ offsets, double eps,
+                                                  uint8_t *__restrict__ ok)
+{
+    __shared__ double red[3 * 16];
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], m = offsets[s + 1] - off;
+    const bool r = has_2d_variation_block(x + off, y + off, m, eps, red);
+    if (threadIdx.x == 0)
+        ok[s] = r ? 1 : 0;
+}
+
+// circle_fitting.py:22-32 for T independent triples {x1,y1,x2,y2,x3,y3}
+__global__ void circle3_kernel(const double *__restrict__ tri, int64_t T, double *__restrict__ out,
+                               uint8_t *__restrict__ ok)
+{
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= T)
+        return;
+    const double *p = tri + 6 * t;
+    const double x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], x3 = p[4], y3 = p[5];
+    const double a = 2 * (x2 - x1), b = 2 * (y2 - y1);
+    const double c = ((x2 * x2 + y2 * y2) - x1 * x1) - y1 * y1;
+    const double d = 2 * (x3 - x2), e = 2 * (y3 - y2);
+    const double f = ((x3 * x3 + y3 * y3) - x2 * x2) - y2 * y2;
+    double cx, cy;
+    const double det = solve2x2(a, b, c, d, e, f, cx, cy);
+    ok[t] = fabs(det) >= 1e-12 ? 1 : 0;
+    out[3 * t] = cx;
+    out[3 * t + 1] = cy;
+    out[3 * t + 2] = cr_hypot(x1 - cx, y1 - cy);
+}
+
+// inliers of a slice, in candidate order (candidates[mask], circle_fitting.py:215)
+__global__ __launch_bounds__(256) void compact_inliers_kernel(
+    const double *__restrict__ cand_x, const double *__restrict__ cand_y, const int64_t *__restrict__ cand_offsets,
+    const uint8_t *__restrict__ mask, const int64_t *__restrict__ inl_offsets, double *__restrict__ inl_x,
+    double *__restrict__ inl_y)
+{
+    __shared__ int wsum[4];
+    __shared__ int carry;
+    const int64_t s = blockIdx.x;
+    const int64_t co = cand_offsets[s], m = cand_offsets[s + 1] - co;
+    const int64_t io = inl_offsets[s], want = inl_offsets[s + 1] - io;
+    if (want == 0)
+        return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0)
+        carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < m; base += 256) {
+        const int64_t i = base + tid;
+        const bool in = i < m && mask[co + i] != 0;
+        const unsigned long long bal = __ballot(in);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            wsum[wave] = __popcll(bal);
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < wave; w++)
+            pre += wsum[w];
+        if (in) {
+            inl_x[io + pre + before] = cand_x[co + i];
+            inl_y[io + pre + before] = cand_y[co + i];
+        }
+        __syncthreads();
+        if (tid == 0)
+            carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
+
+int launch_fit(const double *x, const double *y, const int64_t *offsets, int64_t S, int64_t max_len,
+               const struct LmParams &prm, double *kasa_out, double *out, int32_t *iters, int32_t *status,
+               hipStream_t st);
+
+}  // namespace pcfit
+
+using namespace pcfit;
+
+PCFIT_API int pcfit_ovality_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                      int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
+                                      int64_t grid_len, void *stream)
+{
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "ovality: n_slices out of range");
+    if (n_slices == 0)
+        return PCFIT_OK;
+    PCFIT_REQUIRE(x && y && offsets && cxcyr && scal, "ovality: null pointer");
+    PCFIT_REQUIRE(max_slice_len >= 0, "ovality: max_slice_len must be given");
+    if (max_slice_len > OV_CAP) {
+        set_error("ovality: slices of more than %d points are not supported (got %lld)", OV_CAP,
+                  (long long)max_slice_len);
+        return PCFIT_ERR_UNSUPPORTED;
+    }
+    PCFIT_REQUIRE(!dev_uniform || grid_len >= std::max<int64_t>(1024, max_slice_len),
+                  "ovality: grid_len must be >= max(1024, longest slice)");
+    const int cap = (int)std::max<int64_t>(64, (max_slice_len + 63) / 64 * 64);
+    PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ovality_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, OV_CAP * 18));
+    ovality_kernel<<<dim3((unsigned)n_slices), dim3(OV_BLOCK), (size_t)cap * 18, as_stream(stream)>>>(
+        x, y, offsets, cxcyr, cap, scal, dev_uniform, grid_len);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+// ------------------------------------------------- host-pointer entry points
+PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                      double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull,
+                                      int32_t *status, const int64_t *hull_start)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(n_unique && n_hull && status && (total == 0 || (x && y && ux && uy && hull_idx)),
+                  "unique_hull: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dux, duy, dnu, dhi, dnh, dst, dhs, dws;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dux.alloc(total * 8));
+    PCFIT_TRY(duy.alloc(total * 8));
+    PCFIT_TRY(dnu.alloc(n_slices * 8));
+    PCFIT_TRY(dhi.alloc(total * 8));
+    PCFIT_TRY(dnh.alloc(n_slices * 8));
+    PCFIT_TRY(dst.alloc(n_slices * 4));
+    if (hull_start) PCFIT_TRY(dhs.upload(hull_start, n_slices * 8, st));
+    PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, n_slices)));
+    PCFIT_TRY(pcfit_unique_hull_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
+                                          dux.as<double>(), duy.as<double>(), dnu.as<int64_t>(), dhi.as<int64_t>(),
+                                          dnh.as<int64_t>(), dst.as<int32_t>(), dhs.as<int64_t>(), dws.p, dws.bytes,
+                                          st));
+    PCFIT_TRY(dux.download(ux, total * 8, st));
+    PCFIT_TRY(duy.download(uy, total * 8, st));
+    PCFIT_TRY(dnu.download(n_unique, n_slices * 8, st));
+    PCFIT_TRY(dhi.download(hull_idx, total * 8, st));
+    PCFIT_TRY(dnh.download(n_hull, n_slices * 8, st));
+    PCFIT_TRY(dst.download(status, n_slices * 4, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_ovality_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                  const double *cxcyr, double *scal, double *dev_uniform, int64_t grid_len)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(cxcyr && scal && (total == 0 || (x && y)), "ovality: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dfit, dsc, ddev;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
+    PCFIT_TRY(dsc.alloc(n_slices * 40));
+    if (dev_uniform) PCFIT_TRY(ddev.alloc((size_t)n_slices * grid_len * 8));
+    PCFIT_TRY(pcfit_ovality_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
+                                      dfit.as<double>(), dsc.as<double>(), ddev.as<double>(), grid_len, st));
+    PCFIT_TRY(dsc.download(scal, n_slices * 40, st));
+    if (dev_uniform) PCFIT_TRY(ddev.download(dev_uniform, (size_t)n_slices * grid_len * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                 double inlier_tol, int32_t max_trials, double min_inliers_frac,
+                                 const double *r_range, double huber_delta, int32_t use_hull,
+                                 const int64_t *hull_start, uint64_t seed, int32_t *status, double *fit, double *ux,
+                                 double *uy, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                                 double *cand_y, uint8_t *mask, double *radius, double *theta,
+                                 int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    const int64_t S = n_slices;
+    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "hybrid: null pointer");
+    PCFIT_REQUIRE(total == 0 || (x && y && ux && uy && cand_x && cand_y && mask && radius && theta),
+                  "hybrid: null pointer");
+    PCFIT_REQUIRE(max_trials >= 0, "hybrid: max_trials negative");
+    hipStream_t st = nullptr;
+
+    // 1. distinct points, rank check, hull
+    DevBuf dx, dy, doff, dux, duy, dnu, dhi, dnh, dst, dhs, dws;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (S + 1) * 8, st));
+    PCFIT_TRY(dux.alloc(total * 8));
+    PCFIT_TRY(duy.alloc(total * 8));
+    PCFIT_TRY(dnu.alloc(S * 8));
+    PCFIT_TRY(dhi.alloc(total * 8));
+    PCFIT_TRY(dnh.alloc(S * 8));
+    PCFIT_TRY(dst.alloc(S * 4));
+    if (hull_start) PCFIT_TRY(dhs.upload(hull_start, S * 8, st));
+    PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, S)));
+    PCFIT_TRY(pcfit_unique_hull_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), S, max_len,
+                                          dux.as<double>(), duy.as<double>(), dnu.as<int64_t>(), dhi.as<int64_t>(),
+                                          dnh.as<int64_t>(), dst.as<int32_t>(), dhs.as<int64_t>(), dws.p, dws.bytes,
+                                          st));
+    std::vector<int64_t> n_hull(S);
+    PCFIT_TRY(dnu.download(n_unique, S * 8, st));
+    PCFIT_TRY(dnh.download(n_hull.data(), S * 8, st));
+    PCFIT_TRY(dst.download(status, S * 4, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+
+    // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
+    int64_t max_cand = 0;
+    cand_offsets[0] = 0;
+    for (int64_t s = 0; s < S; s++) {
+        // fewer than 3 points before deduplication is a failure too (circle_fitting.py:178)
+        if (offsets[s + 1] - offsets[s] < 3) status[s] = PCFIT_ST_SPARSE;
+        int64_t m = 0;
+        if (status[s] == PCFIT_ST_OK) m = (use_hull && n_hull[s] >= 3) ? n_hull[s] : n_unique[s];
+        cand_offsets[s + 1] = cand_offsets[s] + m;
+        max_cand = std::max(max_cand, m);
+    }
+    const int64_t n_cand = cand_offsets[S];
+    PCFIT_TRY(dst.upload(status, S * 4, st));
+    DevBuf dco, dcx, dcy;
+    PCFIT_TRY(dco.upload(cand_offsets, (S + 1) * 8, st));
+    PCFIT_TRY(dcx.alloc(n_cand * 8));
+    PCFIT_TRY(dcy.alloc(n_cand * 8));
+    gather_candidates_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dux.as<double>(), duy.as<double>(),
+                                                                     doff.as<int64_t>(), dhi.as<int64_t>(),
+                                                                     dco.as<int64_t>(), use_hull ? 1 : 0,
+                                                                     dcx.as<double>(), dcy.as<double>(),
+                                                                     dst.as<int32_t>());
+    PCFIT_LAUNCH_CHECK();
+
+    // 3. RANSAC on the candidates: one sampling table per distinct candidate count
+    uint64_t state[4];
+    PCFIT_TRY(pcfit_seed_state(seed, state));
+    std::map<int64_t, int32_t> table_id;
+    std::vector<int32_t> of_slice(S, 0), tables;
+    for (int64_t s = 0; s < S; s++) {
+        const int64_t m = cand_offsets[s + 1] - cand_offsets[s];
+        if (m < 3) continue;
+        auto it = table_id.find(m);
+        if (it == table_id.end()) {
+            it = table_id.emplace(m, (int32_t)table_id.size()).first;
+            tables.resize(tables.size() + (size_t)max_trials * 3);
+            PCFIT_TRY(pcfit_choice3_table(state, m, max_trials, tables.data() + (size_t)it->second * max_trials * 3));
+        }
+        of_slice[s] = it->second;
+    }
+    DevBuf dtab, dof, dmodel, dscore, dbest, dmask, drst, drws;
+    PCFIT_TRY(dtab.upload(tables.data(), tables.size() * 4, st));
+    PCFIT_TRY(dof.upload(of_slice.data(), S * 4, st));
+    PCFIT_TRY(dmodel.alloc(S * 24));
+    PCFIT_TRY(dscore.alloc(S * 4));
+    PCFIT_TRY(dbest.alloc(S * 4));
+    PCFIT_TRY(dmask.alloc(n_cand));
+    PCFIT_TRY(drst.alloc(S * 4));
+    PCFIT_TRY(drws.alloc(pcfit_ransac_workspace_bytes(S)));
+    PCFIT_TRY(pcfit_ransac_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, inlier_tol, max_trials,
+                                     min_inliers_frac, r_range, dtab.as<int32_t>(), dof.as<int32_t>(),
+                                     dmodel.as<double>(), dscore.as<int32_t>(), dbest.as<int32_t>(),
+                                     dmask.as<uint8_t>(), drst.as<int32_t>(), drws.p, drws.bytes, st));
+    std::vector<int32_t> score(S), rst(S), st2(S);
+    PCFIT_TRY(dscore.download(score.data(), S * 4, st));
+    PCFIT_TRY(drst.download(rst.data(), S * 4, st));
+    PCFIT_TRY(dst.download(st2.data(), S * 4, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+
+    // 4. inliers -> Kasa start -> LM (circle_fitting.py:215-222)
+    std::vector<int64_t> inl_off(S + 1, 0);
+    int64_t max_inl = 0;
+    for (int64_t s = 0; s < S; s++) {
+        if (status[s] == PCFIT_ST_OK && st2[s] != PCFIT_ST_OK) status[s] = st2[s];        // candidates rank deficient
+        if (status[s] == PCFIT_ST_OK && rst[s] != PCFIT_ST_OK) status[s] = PCFIT_ST_RANSAC;
+        const int64_t k = status[s] == PCFIT_ST_OK ? score[s] : 0;
+        inl_off[s + 1] = inl_off[s] + k;
+        max_inl = std::max(max_inl, k);
+    }
+    DevBuf dio, dix, diy, dfit;
+    PCFIT_TRY(dio.upload(inl_off.data(), (S + 1) * 8, st));
+    PCFIT_TRY(dix.alloc(inl_off[S] * 8));
+    PCFIT_TRY(diy.alloc(inl_off[S] * 8));
+    PCFIT_TRY(dfit.alloc(S * 24));
+    compact_inliers_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dcx.as<double>(), dcy.as<double>(),
+                                                                   dco.as<int64_t>(), dmask.as<uint8_t>(),
+                                                                   dio.as<int64_t>(), dix.as<double>(),
+                                                                   diy.as<double>());
+    PCFIT_LAUNCH_CHECK();
+    PCFIT_TRY(pcfit_fit_batch_dev(dix.as<double>(), diy.as<double>(), dio.as<int64_t>(), S, max_inl, huber_delta, 100,
+                                  1e-2, 1e-10, 1e-12, nullptr, dfit.as<double>(), nullptr, nullptr, st));
+
+    // 5. metrics on the candidates about the fitted circle (analyzer.py:83-95)
+    DevBuf dth, drad, drm, dam, dov, ddev;
+    PCFIT_TRY(dth.alloc(n_cand * 8));
+    PCFIT_TRY(drad.alloc(n_cand * 8));
+    PCFIT_TRY(drm.alloc(S * 16));
+    PCFIT_TRY(dam.alloc(S * 16));
+    PCFIT_TRY(dov.alloc(S * 40));
+    if (dev_uniform) PCFIT_TRY(ddev.alloc((size_t)S * grid_len * 8));
+    PCFIT_TRY(pcfit_residuals_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, dfit.as<double>(),
+                                        dth.as<double>(), nullptr, drad.as<double>(), 0, nullptr, nullptr,
+                                        drm.as<double>(), dam.as<int64_t>(), st));
+    PCFIT_TRY(pcfit_ovality_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, max_cand,
+                                      dfit.as<double>(), dov.as<double>(), ddev.as<double>(), grid_len, st));
+
+    PCFIT_TRY(dfit.download(fit, S * 24, st));
+    PCFIT_TRY(dux.download(ux, total * 8, st));
+    PCFIT_TRY(duy.download(uy, total * 8, st));
+    PCFIT_TRY(dcx.download(cand_x, n_cand * 8, st));
+    PCFIT_TRY(dcy.download(cand_y, n_cand * 8, st));
+    PCFIT_TRY(dmask.download(mask, n_cand, st));
+    PCFIT_TRY(drad.download(radius, n_cand * 8, st));
+    PCFIT_TRY(dth.download(theta, n_cand * 8, st));
+    PCFIT_TRY(dam.download(argmax_argmin, S * 16, st));
+    PCFIT_TRY(dov.download(ov_scal, S * 40, st));
+    if (dev_uniform) PCFIT_TRY(ddev.download(dev_uniform, (size_t)S * grid_len * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                     double eps, uint8_t *ok)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(ok && (total == 0 || (x && y)), "rank_check: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dok;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dok.alloc(n_slices));
+    rank_kernel<<<dim3((unsigned)n_slices), dim3(256), 0, st>>>(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(),
+                                                               eps, dok.as<uint8_t>());
+    PCFIT_LAUNCH_CHECK();
+    PCFIT_TRY(dok.download(ok, n_slices, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, uint8_t *ok)
+{
+    PCFIT_REQUIRE(n_triples >= 0, "circle3: negative count");
+    if (n_triples == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(triples && out && ok, "circle3: null pointer");
+    hipStream_t st = nullptr;
+    DevBuf dt, dout, dok;
+    PCFIT_TRY(dt.upload(triples, n_triples * 48, st));
+    PCFIT_TRY(dout.alloc(n_triples * 24));
+    PCFIT_TRY(dok.alloc(n_triples));
+    circle3_kernel<<<dim3((unsigned)((n_triples + 255) / 256)), dim3(256), 0, st>>>(dt.as<double>(), n_triples,
+                                                                                  dout.as<double>(),
+                                                                                  dok.as<uint8_t>());
+    PCFIT_LAUNCH_CHECK();
+    PCFIT_TRY(dout.download(out, n_triples * 24, st));
+    PCFIT_TRY(dok.download(ok, n_triples, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}

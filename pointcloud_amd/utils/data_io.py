@@ -1,0 +1,44 @@
+"""Text loading and CSV export around the GPU path (host code; the formats
+follow the reference: utils/data_io.py:8-47).  These are the steps before and
+after the hot path; they stay on the host."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def load_txt_points(path: str) -> np.ndarray:
+    """Tolerant XYZ reader.  Reference: utils/data_io.py:8-27 - blank lines and
+    lines starting with '#', '//' or ';' are skipped, commas count as blanks,
+    the first three fields must parse as floats, anything else is ignored."""
+    rows = []
+    with open(path, "r", encoding="utf-8", errors="ignore") as fh:
+        for raw in fh:
+            text = raw.strip()
+            if not text or text.startswith(("#", "//", ";")):
+                continue
+            fields = text.replace(",", " ").split()
+            if len(fields) < 3:
+                continue
+            try:
+                rows.append((float(fields[0]), float(fields[1]), float(fields[2])))
+            except Exception:
+                continue
+    if not rows:
+        raise RuntimeError("No valid XYZ lines found in TXT.")
+    return np.asarray(rows, dtype=np.float64)
+
+
+def save_results(results: list, points: list, output_dir: str):
+    """slice_results.csv (sorted by z_center) and slice_points.csv (sorted by
+    z_center, theta), '%.6f' floats.  Reference: utils/data_io.py:29-47."""
+    import pandas as pd
+
+    if not results:
+        return
+    table = pd.DataFrame(results).sort_values("z_center").reset_index(drop=True)
+    table.to_csv(os.path.join(output_dir, "slice_results.csv"), index=False, float_format="%.6f")
+    if points:
+        edge = pd.concat(points, ignore_index=True).sort_values(["z_center", "theta"]).reset_index(drop=True)
+        edge.to_csv(os.path.join(output_dir, "slice_points.csv"), index=False, float_format="%.6f")

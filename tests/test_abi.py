@@ -1,0 +1,117 @@
+"""CPU-only checks of the shipped library's boundary: it loads, exports every
+symbol include/pcfit.h declares, rejects bad arguments without touching a GPU,
+and its host-side sampling tables equal numpy's."""
+import ctypes as C
+import inspect
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+from pointcloud_amd import _ffi as F
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "pcfit.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(pcfit_\w+)\s*\(", text))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(F.SO_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for name in syms:
+        assert hasattr(L, name), name
+    assert syms == set(F.SIGNATURES), syms ^ set(F.SIGNATURES)
+    assert F.lib().pcfit_version() == 100
+
+
+def test_seed_state_and_choice3_tables_equal_numpy():
+    for seed in (42, 0, 1, 7, 123456789, 2**40 + 5, 2**64 - 1):
+        assert np.array_equal(F.seed_state(seed), F.seed_state_from_numpy(seed)), seed
+    g = load_golden("choice3")
+    for key in g.files:
+        if key == "meta":
+            continue
+        if key.startswith("seed"):
+            assert np.array_equal(F.choice3_table(500, 32, int(key[4:].split("_")[0])), g[key]), key
+        elif key == "n92_t4000":
+            assert np.array_equal(F.choice3_table(92, 4000), g[key])
+        else:
+            assert np.array_equal(F.choice3_table(int(key[1:]), 64), g[key]), key
+    for n in (3, 17, 1 << 20):
+        gen = np.random.default_rng(42)
+        want = np.array([gen.choice(n, size=3, replace=False) for _ in range(200)])
+        assert np.array_equal(F.choice3_table(n, 200), want)
+
+
+def test_argument_errors_are_reported_not_fatal():
+    L = F.lib()
+    out = np.zeros(6, np.int32)
+    st = F.seed_state(42)
+    assert L.pcfit_choice3_table(st.ctypes.data, 2, 2, out.ctypes.data) == -1
+    assert b"n must be" in L.pcfit_last_error()
+    assert L.pcfit_kasa_batch_dev(None, None, None, 5, 0, None, None, None) == -1
+    assert L.pcfit_residuals_batch_dev(None, None, None, 1, None, None, None, None, 100000, None, None, None, None,
+                                       None) == -1
+    assert L.pcfit_bin_count_dev(None, 10, None, None, 1 << 20, None, None, None, 0, None) == -4
+    with pytest.raises(ValueError):
+        F.as_csr(np.zeros(4), np.zeros(3), None)
+    off = np.array([0, 3, 2], np.int64)            # decreasing offsets: rejected on the host
+    with pytest.raises(F.PcfitError, match="non-decreasing"):
+        F.kasa_batch(np.zeros(2), np.zeros(2), off[[0, 1, 2]] * 0 + np.array([0, 3, 2]))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(F, "_lib", None)
+    monkeypatch.setattr(F, "SO_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(F.PcfitError, match="no CPU fallback"):
+        F.lib()
+
+
+REFERENCE_SIGNATURES = {
+    # reference: utils/circle_fitting.py:14,22,35,57-65,112-119,146-156; utils/boundary.py:7,44,56-58
+    "circle_fitting._has_enough_2d_variation": "(xy, eps=1e-12)",
+    "circle_fitting._circle_from_3pts": "(p1, p2, p3)",
+    "circle_fitting.fit_circle_pratt": "(x, y)",
+    "circle_fitting.lm_circle_geometric": "(x, y, cx0, cy0, r0, huber_delta=1.0, max_iter=100, lm_lambda0=0.01, "
+                                          "tol_update=1e-10, tol_cost=1e-12)",
+    "circle_fitting._ransac_circle": "(xy, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None, "
+                                     "rng_seed=42)",
+    "circle_fitting.fit_circle_hybrid_at_z": "(points_xyz, z_elevation, z_tolerance, inlier_tol=0.5, max_trials=4000, "
+                                             "min_inliers_frac=0.1, r_range=None, huber_delta=1.0, "
+                                             "use_hull_vertices_only=True, *, hull_start=None)",
+    "boundary.boundary_by_angle_max": "(points_xy, center=None, bins=720)",
+    "boundary.boundary_by_convex_hull": "(points_xy)",
+    "boundary.ovality_and_fourier": "(x, y, center_x, center_y, radius)",
+}
+
+
+def test_dropin_signatures_match_the_reference():
+    from pointcloud_amd.utils import boundary, circle_fitting
+    mods = {"circle_fitting": circle_fitting, "boundary": boundary}
+    for dotted, want in REFERENCE_SIGNATURES.items():
+        mod, name = dotted.split(".")
+        sig = inspect.signature(getattr(mods[mod], name))
+        got = "(" + ", ".join(
+            ("*, " if p.kind is p.KEYWORD_ONLY and i and list(sig.parameters.values())[i - 1].kind is not p.KEYWORD_ONLY
+             else "") + p.name + ("" if p.default is p.empty else f"={p.default!r}")
+            for i, p in enumerate(sig.parameters.values())) + ")"
+        assert got == want, (dotted, got)
+    from pointcloud_amd import Config, CylinderAnalyzer
+    import dataclasses
+    fields = [(f.name, f.default) for f in dataclasses.fields(Config)]
+    assert fields == [("z_step", 2.0), ("max_points_for_speed", 1_000_000), ("min_points_per_slice", 1000),
+                      ("inlier_quantile", 0.80), ("boundary_method", "angle_max"), ("angle_bins", 720),
+                      ("draw_per_slice_images", True), ("slice_plot_sample_points", 30000), ("overlay_all", True),
+                      ("z_min", None), ("z_max", None)]                       # reference: analyzer.py:17-30
+    for meth in ("process_slice", "analyze_file", "analyze_with_progress", "calculate_z_centers"):
+        assert callable(getattr(CylinderAnalyzer, meth))
+    az = CylinderAnalyzer()
+    pts = np.column_stack([np.zeros(5), np.zeros(5), np.array([0.0, 1.0, 2.0, 3.0, 10.0])])
+    assert np.array_equal(az.calculate_z_centers(pts), np.arange(1.0, 9.0 + 1e-9, 2.0))
+    az = CylinderAnalyzer(Config(z_step=1.0, z_min=2.0, z_max=5.0))
+    assert np.array_equal(az.calculate_z_centers(pts), np.arange(2.5, 4.5 + 1e-9, 1.0))

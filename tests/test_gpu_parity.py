@@ -1,0 +1,395 @@
+"""Parity of the HIP path (through the C ABI of libpcfit_hip.so) with the golden
+vectors recorded from the reference and with the CPU restatements.  Needs a GPU.
+
+Bars: bit-exact for slice membership and order, sampling tables, RANSAC score /
+winning trial / inlier mask / centre, hull vertex sets and order, boundary
+indices, histograms, arg-max / arg-min; <= 1e-9 relative for Kasa and LM
+(LM_TOL lists the two fixtures whose result the reference's own stopping rule
+leaves undetermined beyond ~1e-8); angles within one rounding of 2*pi.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, same_cycle, ulp_diff
+from oracle import native as N
+from oracle import ref_np as R
+from pointcloud_amd import _ffi as F
+
+pytestmark = pytest.mark.gpu
+
+LM_TOL = {1: 1e-7, 10: 1e-4}          # see tests/test_oracle_c.py
+THETA_ABS = 2 * np.spacing(2 * np.pi)  # theta = fmod(atan2 + 2pi, 2pi): atan2 differs by an ulp between libms
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def csr(arrs):
+    off = np.zeros(len(arrs) + 1, np.int64)
+    np.cumsum([len(a) for a in arrs], out=off[1:])
+    cat = np.concatenate(arrs) if arrs else np.zeros((0, 2))
+    return np.ascontiguousarray(cat[:, 0]), np.ascontiguousarray(cat[:, 1]), off
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_circle3_golden():
+    g = load_golden("circle3")
+    out, ok = F.circle3_batch(g["tri"].reshape(-1, 6))
+    assert np.array_equal(ok, g["ok"])
+    good = g["ok"]
+    assert np.array_equal(out[good, :2], g["val"][good, :2])          # LAPACK's 2x2 solve, bit for bit
+    assert np.all(ulp_diff(out[good, 2], g["val"][good, 2]) <= 1)     # hypot: libm is not always correctly rounded
+
+
+def test_kasa_lm_golden_batched():
+    g = load_golden("kasa_lm")
+    sets = [g[f"xy{i}"] for i in range(12)]
+    x, y, off = csr(sets)
+    k, st = F.kasa_batch(x, y, off)
+    assert np.all(st == 0)
+    for i in range(12):
+        assert rel(k[i], g[f"kasa{i}"]) < 1e-11, i
+    init = np.array([g[f"kasa{i}"] for i in range(12)])
+    for key, kw in (("lm", {}), ("lm_d02_", dict(huber_delta=0.2))):
+        out, iters = F.lm_batch(x, y, off, init, **kw)
+        for i in range(12):
+            assert rel(out[i], g[f"{key}{i}"]) < LM_TOL.get(i, 1e-9), (key, i)
+    shifted = init + np.array([0.5, -0.3, 0.0])
+    shifted[:, 2] = init[:, 2] * 1.1
+    out, iters = F.lm_batch(x, y, off, shifted, max_iter=25)
+    for i in range(12):
+        assert rel(out[i], g[f"lm_off{i}"]) < LM_TOL.get(i, 1e-9), i
+        assert iters[i, 0] <= 25
+
+
+def test_ransac_golden_bit_exact():
+    g = load_golden("ransac")
+    for i in range(11):
+        xy = g[f"xy{i}"]
+        tol, trials, frac, r0, r1 = g[f"par{i}"]
+        rr = None if r0 < 0 else (r0, r1)
+        r = F.ransac_batch(xy[:, 0], xy[:, 1], None, tol, int(trials), frac, rr)
+        assert (r["status"][0] == 0) == bool(g[f"ok{i}"]), i
+        if r["status"][0]:
+            continue
+        assert g[f"margin{i}"] > 1e-9
+        assert r["score"][0] == int(g[f"score{i}"])
+        assert r["best_trial"][0] == int(g[f"best_trial{i}"])
+        assert np.array_equal(r["mask"], g[f"mask{i}"])
+        assert np.array_equal(r["model"][0, :2], g[f"model{i}"][:2])
+        assert ulp_diff(r["model"][0, 2], g[f"model{i}"][2]) <= 1
+
+
+def test_unique_hull_hybrid_golden():
+    g = load_golden("hull_hybrid")
+    for i in range(10):
+        pts = g[f"pts{i}"]
+        off, x, y, perm = F.bin_slices(pts, [-0.5], [0.5])
+        keep = (pts[:, 2] >= -0.5) & (pts[:, 2] <= 0.5)
+        assert np.array_equal(perm, np.nonzero(keep)[0])
+        h = F.unique_hull_batch(x, y, off)
+        nu, nh = int(h["n_unique"][0]), int(h["n_hull"][0])
+        uniq = g[f"uniq{i}"]
+        assert np.array_equal(np.stack([h["ux"][:nu], h["uy"][:nu]], 1), uniq)
+        q = g[f"qhull{i}"]
+        if len(uniq) >= 3:
+            assert h["hull_idx"][0] == 0
+            assert same_cycle(h["hull_idx"][:nh], q), i
+            assert np.array_equal(h["hull_idx"][:nh], N.hull(uniq))
+        # with Qhull's first vertex handed over, everything downstream is the reference's
+        start = np.array([int(q[0])]) if len(q) else None
+        hy = F.hybrid_batch(x, y, off, max_trials=800, hull_start=start)
+        assert (hy["status"][0] == 0) == bool(g[f"ok{i}"]), i
+        if hy["status"][0]:
+            continue
+        assert np.array_equal(np.stack([hy["cand_x"], hy["cand_y"]], 1), g[f"cand{i}"])
+        assert np.array_equal(hy["mask"], g[f"mask{i}"])
+        assert rel(hy["fit"][0], g[f"fit{i}"]) < 1e-9
+
+
+def _ring50k():
+    gen = np.random.default_rng(64)
+    th = gen.uniform(0, 2 * np.pi, 50000)
+    rr = 10.0 + gen.normal(0, 0.05, 50000)
+    return np.stack([3.0 + rr * np.cos(th), -2.0 + rr * np.sin(th)], axis=1)
+
+
+def test_boundary_golden():
+    from pointcloud_amd.utils import boundary as B
+    from pointcloud_amd.utils import residuals as RS
+    g = load_golden("boundary")
+    for i in range(5):
+        if f"xy{i}" in g.files:
+            xy = g[f"xy{i}"]
+        else:
+            xy = _ring50k()
+            assert hashlib.sha256(xy.tobytes()).hexdigest() == str(g[f"xy{i}_sha"])
+        bins = int(g[f"bins{i}"])
+        assert np.array_equal(B.boundary_by_angle_max(xy, center=(3.0, -2.0), bins=bins), xy[g[f"idx_c{i}"]]), i
+        assert np.array_equal(B.boundary_by_angle_max(xy, bins=bins), xy[g[f"idx_auto{i}"]]), i
+    for i in range(4):
+        xy = g[f"ov_xy{i}"]
+        fit = g[f"ov_fit{i}"]
+        ov = B.ovality_and_fourier(xy[:, 0], xy[:, 1], *fit)
+        want = g[f"ov_scal{i}"]
+        got = [ov["Rmax"], ov["Rmin"], ov["ovality_abs"], ov["ovality_pct"]]
+        assert rel(got, want[:4]) < 1e-12
+        assert abs(ov["k2_amp"] - want[4]) < 1e-12 * np.abs(g[f"ov_dev{i}"]).max() + 1e-9 * want[4]
+        assert np.max(np.abs(ov["dev_uniform"] - g[f"ov_dev{i}"])) < 1e-12
+        assert np.array_equal(ov["theta"], np.linspace(0, 2 * np.pi, max(1024, len(xy)), endpoint=False))
+        th, dr = RS.residual_profile(xy, *fit)
+        assert np.max(np.abs(th - g[f"rp_theta{i}"])) <= THETA_ABS
+        assert np.max(np.abs(dr - g[f"rp_dr{i}"])) <= 2 * np.spacing(fit[2])
+
+
+# ------------------------------------------------------------------ against the C restatement
+def test_kernels_match_c_oracle_ragged():
+    gen = np.random.default_rng(3)
+    x, y, _ = R.make_slices(1, 60000, seed=2, outlier_frac=0.3)
+    cuts = np.sort(gen.integers(0, 60000, 40))
+    off = np.concatenate([[0], cuts, [60000]]).astype(np.int64)
+    off[5] = off[4]                     # an empty slice
+    off[9] = off[8] + 2                 # a slice of two points
+    S = len(off) - 1
+    k, st = F.kasa_batch(x, y, off)
+    r = F.ransac_batch(x, y, off, max_trials=300)
+    fit = np.tile([3.01, -1.98, 10.02], (S, 1))
+    res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_radius=True)
+    sel = F.angle_max_batch(x, y, off, fit, bins=720)
+    for s in range(S):
+        sl = slice(off[s], off[s + 1])
+        xy = np.stack([x[sl], y[sl]], 1)
+        so, ko = N.kasa(x[sl], y[sl])
+        assert so == st[s]
+        if so == 0:
+            assert rel(k[s], ko) < 1e-11
+        o = N.ransac(xy, trials=300)
+        assert (o["status"], o["score"], o["best_trial"]) == (r["status"][s], r["score"][s], r["best_trial"][s]), s
+        if o["status"] == 0:
+            assert np.array_equal(o["mask"], r["mask"][sl]) and np.array_equal(o["model"], r["model"][s])
+        o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5)
+        assert np.array_equal(o["dr"], res["dr"][sl])
+        assert np.array_equal(o["hist"], res["hist"][s])
+        assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
+        if len(xy):
+            assert (o["rmax"], o["rmin"]) == (res["rmax"][s], res["rmin"][s])
+            assert np.max(np.abs(o["theta"] - res["theta"][sl])) <= THETA_ABS
+            assert np.array_equal(res["radius"][sl], N.polar(xy, fit[s][0], fit[s][1])[1])
+        assert np.array_equal(N.angle_max(xy, fit[s][0], fit[s][1], 720), sel[s]), s
+
+
+def test_ransac_interval_test_equals_literal_test_on_awkward_scales():
+    # radii and tolerances where (R +- tol)^2 sits near rounding boundaries, tiny and huge scales
+    gen = np.random.default_rng(5)
+    for scale, tol in ((1.0, 0.5), (1e-3, 2e-4), (1e6, 0.125), (1.0, 0.0), (1.0, 30.0), (7.0, 1e-9)):
+        th = gen.uniform(0, 2 * np.pi, 700)
+        rr = scale * (1 + gen.normal(0, 0.02, 700))
+        xy = np.stack([scale * 3 + rr * np.cos(th), -scale * 2 + rr * np.sin(th)], 1)
+        xy[::7] += gen.normal(0, scale, (100, 2))
+        r = F.ransac_batch(xy[:, 0], xy[:, 1], None, tol, 200, 0.1)
+        o = N.ransac(xy, tol, 200, 0.1)
+        assert (o["status"], o["score"], o["best_trial"]) == (r["status"][0], r["score"][0], r["best_trial"][0]), (scale, tol)
+        if o["status"] == 0:
+            assert np.array_equal(o["mask"], r["mask"])
+
+
+def test_bin_slices_stable_and_exact():
+    pts = R.make_cylinder(300_000, 57, seed=9, outlier_frac=0.05)
+    pts[5:119, 2] = np.repeat(np.arange(0.0, 114.0, 2.0), 2)      # points exactly on shared window edges
+    pts[200:210, 2] = np.nextafter(np.arange(2.0, 22.0, 2.0), 0)  # one ulp below an edge
+    pts[210:220, 2] = np.nextafter(np.arange(2.0, 22.0, 2.0), 1e9)
+    pts[300, 2] = np.nan
+    zc, lo, hi = R.slice_windows(np.nanmin(pts[:, 2]), np.nanmax(pts[:, 2]), 2.0)
+    off, x, y, perm = F.bin_slices(pts, lo, hi)
+    o_ref, p_ref = N.bin_slices(pts, lo, hi)
+    assert np.array_equal(off, o_ref)
+    assert np.array_equal(perm, p_ref)                             # same members, same order
+    assert np.array_equal(x, pts[perm, 0]) and np.array_equal(y, pts[perm, 1])
+    assert off[-1] > np.count_nonzero((pts[:, 2] >= lo[0]) & (pts[:, 2] <= hi[-1]))
+    # many windows, few points each; and one window only
+    zc, lo, hi = R.slice_windows(0.0, 114.0, 0.01)
+    off, x, y, perm = F.bin_slices(pts[:50_000], lo, hi)
+    o_ref, p_ref = N.bin_slices(pts[:50_000], lo, hi)
+    assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
+    off, x, y, perm = F.bin_slices(pts, [10.0], [10.0])            # zero-width window
+    assert np.array_equal(perm, np.nonzero(pts[:, 2] == 10.0)[0])
+
+
+def test_degenerate_slices():
+    same = np.tile([[1.5, -2.5]], (10, 1))
+    line = np.stack([np.arange(12.0), 2 * np.arange(12.0)], 1)
+    axis = np.stack([np.arange(9.0), np.zeros(9)], 1)
+    x, y, off = csr([same, line, axis, np.zeros((0, 2)), np.array([[0.0, 0.0], [1.0, 1.0]])])
+    k, st = F.kasa_batch(x, y, off)
+    assert list(st) == [4, 0, 4, 1, 1] or list(st) == [4, 4, 4, 1, 1]
+    assert np.allclose(k[0], [1.5, -2.5, 0.0])                     # minimum-norm solution, as lstsq gives
+    assert np.all(np.isnan(k[3])) and np.all(np.isnan(k[4]))
+    ok = F.rank_check_batch(x, y, off)
+    assert list(ok) == [False, False, False, False, False]
+    h = F.hybrid_batch(x, y, off, max_trials=50)
+    assert list(h["status"]) == [1, 2, 2, 1, 1]
+    r = F.ransac_batch(x, y, off, max_trials=50)
+    assert list(r["status"]) == [3, 3, 3, 1, 1] and list(r["score"]) == [-1, -1, -1, -1, -1]
+
+
+def test_two_runs_are_bitwise_identical():
+    x, y, off = R.make_slices(50, 3000, seed=8, outlier_frac=0.2, jitter=0.1)
+    a = F.hybrid_batch(x, y, off, max_trials=500)
+    b = F.hybrid_batch(x, y, off, max_trials=500)
+    for key in ("fit", "cand_x", "cand_y", "mask", "radius", "theta", "ov", "status"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key
+
+
+# ------------------------------------------------------------------ drop-in layer
+SCALARS = ["z_center", "z_low", "z_high", "n_points_slice", "n_edge", "cx", "cy", "R", "Rmax", "Rmin",
+           "x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin", "ovality_abs", "ovality_pct", "k2_amp", "cost"]
+
+
+def analyzer_points():
+    pts = R.make_cylinder(50_000, 20, seed=5, outlier_frac=0.02)
+    pts[10:40, 2] = np.repeat(np.arange(2.0, 32.0, 2.0), 2)
+    return pts
+
+
+def test_analyzer_matches_reference_run():
+    from pointcloud_amd import Config, CylinderAnalyzer
+    g = load_golden("analyzer")
+    pts = analyzer_points()
+    assert hashlib.sha256(pts.tobytes()).hexdigest() == str(g["pts_sha"])
+    az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=1000))
+    assert np.array_equal(az.calculate_z_centers(pts), g["z_centers"])
+    prog = []
+    res = az.analyze_with_progress(pts, progress_callback=prog.append)
+    assert sorted(prog) == list(g["progress_sorted"]) and prog == sorted(prog) and prog[-1] == 100
+    assert len(res) == int(g["n_results"])
+    assert list(res[0].keys()) == list(g["keys"])
+    mine = np.array([[r[k] for k in SCALARS] for r in res], dtype=float)
+    ref = g["scalars"]
+    exact = [SCALARS.index(k) for k in ("z_center", "z_low", "z_high", "n_points_slice", "n_edge", "cost")]
+    assert np.array_equal(mine[:, exact], ref[:, exact])
+    off = 0
+    for r, n in zip(res, g["bpts_len"]):
+        want = [tuple(p) for p in g["bpts_cat"][off:off + n]]
+        assert same_cycle([tuple(p) for p in r["boundary_points"]], want)   # same hull, other first vertex
+        off += n
+    # the candidate walk starts at another vertex than Qhull's, so RANSAC draws other triples: the
+    # fit agrees to rounding wherever the consensus does not depend on the draw, and differs in the
+    # few slices whose hull holds outliers (same slices and sizes as the numpy restatement)
+    fitc = [SCALARS.index(k) for k in ("cx", "cy", "R")]
+    dev = np.abs(mine[:, fitc] - ref[:, fitc]).max(axis=1) / ref[:, SCALARS.index("R")]
+    assert np.median(dev) < 1e-9 and np.count_nonzero(dev > 1e-9) <= 4 and dev.max() < 0.05
+    oracle = R.analyze(pts, z_step=2.0, min_points_per_slice=1000)
+    theirs = np.array([[r[k] for k in SCALARS] for r in oracle], dtype=float)
+    assert rel(mine[:, fitc], theirs[:, fitc]) < 1e-9                      # same start vertex: same fits
+    for col in ("Rmax", "Rmin", "ovality_abs", "ovality_pct"):
+        c = SCALARS.index(col)
+        assert rel(mine[:, c], theirs[:, c]) < 1e-9
+    for col in ("x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin"):
+        c = SCALARS.index(col)
+        assert np.array_equal(mine[:, c], theirs[:, c])
+    c = SCALARS.index("k2_amp")
+    assert np.max(np.abs(mine[:, c] - theirs[:, c])) < 1e-12
+
+    az2 = CylinderAnalyzer(Config(z_step=4.0, min_points_per_slice=100, z_min=3.0, z_max=29.0))
+    assert np.array_equal(az2.calculate_z_centers(pts), g["cfg_z_centers"])
+    res2 = az2.analyze_with_progress(pts)
+    mine2 = np.array([[r[k] for k in SCALARS] for r in res2], dtype=float)
+    assert np.array_equal(mine2[:, exact], g["cfg_scalars"][:, exact])
+
+
+def test_process_slice_contract():
+    from pointcloud_amd import Config, CylinderAnalyzer
+    g = load_golden("analyzer")
+    pts = analyzer_points()
+    az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=1000))
+    zc = g["z_centers"]
+    (res, cand, slc, fit, ov), edge, warn = az.process_slice(pts, zc[3])
+    assert warn is None
+    assert list(edge.columns) == list(g["ps_edge_cols"])
+    assert len(slc) == int(g["ps_slc_len"]) and res["n_points_slice"] == len(slc)
+    ref_edge = g["ps_edge"]
+    assert same_cycle(list(zip(edge["x"], edge["y"])), [tuple(p) for p in ref_edge[:, 1:3]])
+    assert set(ov) == {"Rmax", "Rmin", "ovality_abs", "ovality_pct", "k2_amp", "theta", "dev_uniform"}
+    assert len(ov["theta"]) == 1024 and len(ov["dev_uniform"]) == 1024
+    # the per-candidate columns are those of the reference for the same candidate, whatever the first vertex
+    lut = {tuple(p): k for k, p in enumerate(map(tuple, ref_edge[:, 1:3]))}
+    order = np.array([lut[(a, b)] for a, b in zip(edge["x"], edge["y"])])
+    if abs(res["cx"] - g["ps_scal"][SCALARS.index("cx")]) < 1e-9:
+        assert np.max(np.abs(edge["radius"].to_numpy() - ref_edge[order, 3])) < 1e-8
+        assert np.array_equal(edge["inlier"].to_numpy(), ref_edge[order, 5].astype(int))
+    out = az.process_slice(pts[:500], zc[3])
+    assert out[0] is None and out[1] is None and out[2] == str(g["ps_sparse_msg"])
+    with pytest.raises(ValueError, match="Points must be Nx3 array"):
+        az.analyze_with_progress(np.zeros((5, 2)))
+    with pytest.raises(ValueError, match="No points in specified Z range"):
+        CylinderAnalyzer(Config(z_min=1e6, z_max=2e6)).analyze_with_progress(pts)
+
+
+def test_dropin_function_contracts():
+    from pointcloud_amd.utils import circle_fitting as CF
+    from pointcloud_amd.utils import boundary as B
+    with pytest.raises(ValueError, match="Need at least 3 points for Pratt fit"):
+        CF.fit_circle_pratt([0.0, 1.0], [0.0, 1.0])
+    with pytest.raises(ValueError, match=r"points_xyz must be \(N,3\)"):
+        CF.fit_circle_hybrid_at_z(np.zeros((4, 2)), 0.0, 1.0)
+    assert CF.fit_circle_hybrid_at_z(np.zeros((4, 3)) + [0, 0, 5.0], 0.0, 1.0) is None
+    assert CF._ransac_circle(np.zeros((2, 2))) is None
+    assert CF._circle_from_3pts((0, 0), (1, 1), (2, 2)) is None
+    c = CF._circle_from_3pts((1, 0), (0, 1), (-1, 0))
+    assert np.allclose(c, (0, 0, 1))
+    g = load_golden("hull_hybrid")
+    res = CF.fit_circle_hybrid_at_z(g["pts0"], 0.0, 0.5, max_trials=800, hull_start=int(g["qhull0"][0]))
+    assert list(res.keys()) == ["center_x", "center_y", "radius", "inlier_mask", "fit_points_xy", "candidates_xy",
+                                "z_elevation"]
+    assert np.array_equal(res["fit_points_xy"], g["uniq0"]) and np.array_equal(res["candidates_xy"], g["cand0"])
+    assert rel([res["center_x"], res["center_y"], res["radius"]], g["fit0"]) < 1e-9
+    m = CF._ransac_circle(g["cand0"], max_trials=800)
+    assert set(m) == {"score", "cx", "cy", "R", "mask"} and np.array_equal(m["mask"], g["mask0"])
+    with pytest.raises(RuntimeError, match="Too few hull vertices"):
+        B.boundary_by_convex_hull(np.array([[0, 0], [1, 0], [0, 1], [1, 1.0]]))
+    xy = g["uniq1"]
+    hull32 = B.boundary_by_convex_hull(xy)
+    p32 = R.unique_rows(xy.astype(np.float32).astype(np.float64))
+    assert np.array_equal(hull32, p32[R.hull_ccw(p32)])
+
+
+# ------------------------------------------------------------------ full-size configurations
+def test_full_size_fit_residual_pass():
+    """10 000 slices x 8192 points: the whole batch on the GPU, 48 slices replayed on the CPU."""
+    S, n = 10_000, 8192
+    x, y, off = R.make_slices(S, n, seed=1, jitter=0.02)
+    fit_k, st = F.kasa_batch(x, y, off)
+    fit, iters = F.lm_batch(x, y, off, fit_k)
+    res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
+    assert np.all(st == 0) and np.all(iters[:, 0] == 100)
+    assert np.all(res["hist"].sum(axis=1) == n)                   # 10 sigma range holds every point
+    assert abs(np.median(fit[:, 2]) - 10.0) < 0.02
+    for s in np.random.default_rng(0).choice(S, 48, replace=False):
+        sl = slice(off[s], off[s + 1])
+        so, ko = N.kasa(x[sl], y[sl])
+        assert rel(fit_k[s], ko) < 1e-11
+        lo_, it, acc = N.lm(x[sl], y[sl], ko)
+        assert rel(fit[s], lo_) < 1e-9
+        o = N.residuals(np.stack([x[sl], y[sl]], 1), *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
+        assert np.array_equal(o["hist"], res["hist"][s])
+        assert (o["argmax"], o["argmin"], o["rmax"], o["rmin"]) == (res["argmax"][s], res["argmin"][s],
+                                                                    res["rmax"][s], res["rmin"][s])
+
+
+def test_full_size_ransac_30pct_outliers():
+    """10 000 slices x 8192 points, 30 % outliers, 1024 hypotheses: bit-exact consensus on 24 replayed slices."""
+    S, n = 10_000, 8192
+    x, y, off = R.make_slices(S, n, seed=2, outlier_frac=0.30)
+    r = F.ransac_batch(x, y, off, 0.5, 1024, 0.1)
+    assert np.all(r["status"] == 0)
+    assert np.all(r["score"] == np.add.reduceat(r["mask"].astype(np.int64), off[:-1]))
+    assert r["score"].min() > 0.6 * n
+    for s in np.random.default_rng(1).choice(S, 24, replace=False):
+        sl = slice(off[s], off[s + 1])
+        o = N.ransac(np.stack([x[sl], y[sl]], 1), 0.5, 1024, 0.1)
+        assert (o["score"], o["best_trial"]) == (r["score"][s], r["best_trial"][s])
+        assert np.array_equal(o["mask"], r["mask"][sl]) and np.array_equal(o["model"], r["model"][s])
