@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Throughput of the fit + residual pass on MI355X.
+
+One step = one pass of the hot path over one batch of pre-binned slices that is
+already resident in HBM:  Kasa start + LM/Huber refinement (one fused launch,
+pcfit_fit_batch_dev) followed by the residual pass (pcfit_residuals_batch_dev:
+delta-r histogram of 256 bins over +-10 sigma, Rmax / Rmin and their indices).
+Workload at N=1: 10 000 slices x 8192 points, FP64, synthetic noisy cylinder
+(the "1x MI355X batched algebraic+geometric fit" configuration).  With N > 1
+every rank owns its own batch of that size (slices shard with no data exchange;
+weak scaling) and the fitted parameters and histograms of all ranks are
+all-gathered with RCCL, overlapped with the next step's kernels.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from pointcloud_amd import _ffi as F            # noqa: E402
+from pointcloud_amd.synth import make_slices    # noqa: E402
+
+# how the flop figure of the fused fit kernel is counted (per point and pass): building the
+# normal equations = 2 sqrt-class + 1 divide + 9 weighted sums ~ 70 flop, one cost evaluation
+# = 1 sqrt-class + compare + accumulate ~ 30 flop.  100 literal iterations of both = 1e4 flop/pt.
+FLOP_HG_PASS = 70.0
+FLOP_COST_PASS = 30.0
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def cpu_baseline(x, y, off, bins, lo, hi, budget_s=12.0, max_slices=400):
+    """numpy restatement of the same step (Kasa -> LM -> residual histogram), slice after slice,
+    on the host: the stand-in for the reference's CPU path, which cannot travel."""
+    from oracle import ref_np as R
+    t0 = time.perf_counter()
+    done = pts = 0
+    while done < max_slices and time.perf_counter() - t0 < budget_s:
+        sl = slice(off[done], off[done + 1])
+        xs, ys = x[sl], y[sl]
+        k = R.kasa_fit(xs, ys)
+        f = R.lm_huber(xs, ys, *k)
+        theta, r = R.polar(np.stack([xs, ys], 1), f[0], f[1])
+        R.residual_histogram(r - f[2], bins, lo, hi)
+        int(np.argmax(r)), int(np.argmin(r))
+        done += 1
+        pts += xs.size
+    dt = time.perf_counter() - t0
+    return pts / dt, done, dt
+
+
+def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=24):
+    from oracle import native as N
+    n_slices = min(n_slices, len(off) - 1)
+    end = off[n_slices]
+    t0 = time.perf_counter()
+    N.fit_residual_batch(x[:end], y[:end], off[:n_slices + 1], bins, lo, hi)
+    dt = time.perf_counter() - t0
+    return end / dt, n_slices, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--slices", type=int, default=10_000)
+    ap.add_argument("--points", type=int, default=8192)
+    ap.add_argument("--bins", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    L = F.lib()
+
+    S, n, H = a.slices, a.points, a.bins
+    sigma = 0.05
+    lo, hi = -10 * sigma, 10 * sigma
+    xh, yh, offh = make_slices(S, n, seed=1 + rank, sigma=sigma, jitter=0.02)
+    x = torch.from_numpy(xh).to(dev)
+    y = torch.from_numpy(yh).to(dev)
+    off = torch.from_numpy(offh).to(dev)
+    edges = torch.from_numpy(np.linspace(lo, hi, H + 1)).to(dev)
+    kasa = torch.empty(S, 3, dtype=torch.float64, device=dev)
+    fit = [torch.empty(S, 3, dtype=torch.float64, device=dev) for _ in range(2)]
+    hist = torch.empty(S, H, dtype=torch.int64, device=dev)
+    hist32 = [torch.empty(S, H, dtype=torch.int32, device=dev) for _ in range(2)]
+    iters = torch.empty(S, 4, dtype=torch.int32, device=dev)
+    status = torch.empty(S, dtype=torch.int32, device=dev)
+    rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
+    amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
+    if world > 1:
+        g_fit = [torch.empty(world * S, 3, dtype=torch.float64, device=dev) for _ in range(2)]
+        g_hist = [torch.empty(world * S, H, dtype=torch.int32, device=dev) for _ in range(2)]
+    pending = [None, None]
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ev_fit, ev_res = [], []
+
+    def step(i, timed):
+        b = i & 1
+        if pending[b] is not None:                  # buffers of step i-2 are still being gathered
+            for w in pending[b]:
+                w.wait()
+            pending[b] = None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e2 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        F.check(L.pcfit_fit_batch_dev(ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa),
+                                      ptr(fit[b]), ptr(iters), ptr(status), stream))
+        e1.record()
+        F.check(L.pcfit_residuals_batch_dev(ptr(x), ptr(y), ptr(off), S, ptr(fit[b]), None, None, None, H,
+                                            ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream))
+        e2.record()
+        if timed:
+            ev_fit.append((e0, e1))
+            ev_res.append((e1, e2))
+        if world > 1:
+            hist32[b].copy_(hist)
+            pending[b] = [dist.all_gather_into_tensor(g_fit[b], fit[b], async_op=True),
+                          dist.all_gather_into_tensor(g_hist[b], hist32[b], async_op=True)]
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
+
+    for i in range(a.warmup):
+        step(i, False)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, True)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ms_step = dt / a.steps * 1e3
+    fit_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_fit]))
+    res_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_res]))
+    it = iters.cpu().numpy().astype(np.float64)
+    flop_launch = float(n * (FLOP_HG_PASS * it[:, 2].sum() + FLOP_COST_PASS * it[:, 3].sum()))
+    res_bytes = float(S * n * 16)
+
+    if rank == 0:
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
+        out = {
+            "metric": "points fitted/sec (circle fit+residuals)",
+            "value": world * S * n / (dt / a.steps),
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{S} slices x {n} points per GPU, Kasa+LM/Huber fit then residual "
+                                   f"histogram ({H} bins) + Rmax/Rmin, pre-binned CSR, noisy cylinder sigma=0.05",
+                       "slices_per_gpu": S, "points_per_slice": n, "hist_bins": H,
+                       "parallelism": f"slice-sharded x{world}" + (", RCCL all-gather of fits+histograms" if world > 1 else "")},
+            "roofline": {
+                "kernel": "fit_kernel (Kasa + LM, slice in registers)", "bound": "valu_fp64",
+                "achieved": flop_launch / (fit_ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": flop_launch / (fit_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+                "traffic": traffic.get("fit_kernel_bytes"),
+                "avg_launch_ms": fit_ms,
+                "flop_per_point": flop_launch / (S * n),
+                "mean_hg_passes": float(it[:, 2].mean()), "mean_cost_passes": float(it[:, 3].mean()),
+                "algorithmic_hbm_gbs": res_bytes / (fit_ms * 1e-3) / 1e9,
+            },
+            "roofline_hbm": {
+                "kernel": "residuals_kernel", "bound": "hbm",
+                "achieved": res_bytes / (res_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": res_bytes / (res_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic.get("residuals_kernel_bytes"),
+                "avg_launch_ms": res_ms,
+            },
+            "fit_plus_residual_hbm_frac": 2 * res_bytes / ((fit_ms + res_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            rate, k, secs = cpu_baseline(xh, yh, offh, H, lo, hi)
+            out["cpu_baseline"] = {"value": rate, "unit": "points/s", "cores": 1, "kind": "port",
+                                   "sample": f"numpy restatement of the same step on the first {k} slices "
+                                             f"({k * n} points, {secs:.1f} s, one Python thread)"}
+            rate_c, kc, secs_c = cpu_baseline_c(xh, yh, offh, H, lo, hi)
+            out["cpu_baseline_c"] = {"value": rate_c, "unit": "points/s", "cores": 1, "kind": "port",
+                                     "sample": f"plain C restatement (literal 100 iterations) on {kc} slices, {secs_c:.1f} s"}
+            out["gpu_over_cpu"] = out["value"] / rate
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

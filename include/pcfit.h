@@ -100,9 +100,11 @@ int pcfit_kasa_batch_dev(const double *x, const double *y, const int64_t *offset
                          int64_t max_slice_len, double *cxcyr, int32_t *status, void *stream);
 
 /* ---- geometric refinement: lm_circle_geometric, circle_fitting.py:57-109 */
-/* init, out: S*3.  iters (nullable): S*2 = {iterations of the reference loop,
- * accepted steps}.  max_slice_len: largest slice population (lets the launch
- * keep a slice in registers); pass 0 if unknown. */
+/* init, out: S*3.  iters (nullable): S*4 = {iterations the reference loop
+ * runs, accepted steps, passes over the points that built the normal
+ * equations, passes that evaluated a candidate's cost}.  max_slice_len:
+ * largest slice population (lets the launch keep a slice in registers); pass 0
+ * if unknown. */
 int pcfit_lm_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                        int64_t max_slice_len, const double *init, double huber_delta, int32_t max_iter,
                        double lm_lambda0, double tol_update, double tol_cost, double *out, int32_t *iters,

@@ -154,7 +154,7 @@ def lm_batch(x, y, offsets, init, huber_delta=1.0, max_iter=100, lm_lambda0=1e-2
     S = offsets.size - 1
     init = _arr(init, np.float64).reshape(S, 3)
     out = np.zeros((S, 3))
-    iters = np.zeros((S, 2), np.int32)
+    iters = np.zeros((S, 4), np.int32)
     check(lib().pcfit_lm_batch(_p(x), _p(y), _p(offsets), S, _p(init), huber_delta, max_iter, lm_lambda0, tol_update,
                                tol_cost, _p(out), _p(iters)))
     return out, iters

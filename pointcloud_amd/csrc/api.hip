@@ -248,12 +248,12 @@ PCFIT_API int pcfit_lm_batch(const double *x, const double *y, const int64_t *of
     PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
     PCFIT_TRY(dinit.upload(init, n_slices * 24, st));
     PCFIT_TRY(dout.alloc(n_slices * 24));
-    PCFIT_TRY(dit.alloc(n_slices * 8));
+    PCFIT_TRY(dit.alloc(n_slices * 16));
     PCFIT_TRY(pcfit_lm_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
                                  dinit.as<double>(), huber_delta, max_iter, lm_lambda0, tol_update, tol_cost,
                                  dout.as<double>(), dit.as<int32_t>(), st));
     PCFIT_TRY(dout.download(out, n_slices * 24, st));
-    PCFIT_TRY(dit.download(iters, n_slices * 8, st));
+    PCFIT_TRY(dit.download(iters, n_slices * 16, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     return PCFIT_OK;
 }

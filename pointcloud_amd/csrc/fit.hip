@@ -171,17 +171,17 @@ struct LmParams {
 // does too and is rejected with the very same cost, so the loop stops there and
 // reports the iteration count the literal loop would have reached.
 template <int PT>
-__device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds, double par[3], int32_t &iters,
-                         int32_t &accepts)
+__device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds, double par[3], int32_t iters[4])
 {
     double cx = par[0], cy = par[1], rad = par[2];
     double lam = prm.lam0, prev = __longlong_as_double(0x7ff0000000000000ll);
     const double delta = prm.delta;
     double hg[9];   // H00 H01 H02 H11 H12 H22 g0 g1 g2
     bool fresh = false;
-    int32_t it = 0, acc = 0;
+    int32_t it = 0, acc = 0, n_hg = 0, n_cost = 0;
     for (; it < prm.max_iter; it++) {
         if (!fresh) {
+            n_hg++;
 #pragma unroll
             for (int k = 0; k < 9; k++)
                 hg[k] = 0.0;
@@ -227,6 +227,7 @@ __device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds
         double tr = rad + step[2];
         if (!(tr > 1e-12))
             tr = 1e-12;
+        n_cost++;
         double c2[2] = {0.0, 0.0};   // quadratic part, linear part
         P.each([&](double px, double py) {
             const double dx = px - tx, dy = py - ty;
@@ -261,8 +262,10 @@ __device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds
     par[0] = cx;
     par[1] = cy;
     par[2] = rad;
-    iters = it;
-    accepts = acc;
+    iters[0] = it;        // iterations of the literal loop
+    iters[1] = acc;       // accepted steps
+    iters[2] = n_hg;      // passes over the points that built H and g
+    iters[3] = n_cost;    // passes over the points that evaluated a candidate's cost
 }
 
 template <int PT>
@@ -298,15 +301,16 @@ __global__ __launch_bounds__(FIT_BLOCK) void lm_kernel(const double *__restrict_
     SliceView<PT> P;
     P.load(x, y, off, n);
     double c[3] = {init[3 * s], init[3 * s + 1], init[3 * s + 2]};
-    int32_t it = 0, acc = 0;
-    lm_slice(P, prm, lds, c, it, acc);
+    int32_t it[4] = {0, 0, 0, 0};
+    lm_slice(P, prm, lds, c, it);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
         out[3 * s + 2] = c[2];
         if (iters) {
-            iters[2 * s] = it;
-            iters[2 * s + 1] = acc;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                iters[4 * s + k] = it[k];
         }
     }
 }
@@ -331,16 +335,17 @@ __global__ __launch_bounds__(FIT_BLOCK) void fit_kernel(const double *__restrict
         kasa_out[3 * s + 1] = c[1];
         kasa_out[3 * s + 2] = c[2];
     }
-    int32_t it = 0, acc = 0;
+    int32_t it[4] = {0, 0, 0, 0};
     if (st != PCFIT_ST_SPARSE)
-        lm_slice(P, prm, lds, c, it, acc);
+        lm_slice(P, prm, lds, c, it);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
         out[3 * s + 2] = c[2];
         if (iters) {
-            iters[2 * s] = it;
-            iters[2 * s + 1] = acc;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                iters[4 * s + k] = it[k];
         }
         if (status)
             status[s] = st;
