@@ -2,9 +2,10 @@
 """Throughput of the fit + residual pass on MI355X.
 
 One step = one pass of the hot path over one batch of pre-binned slices that is
-already resident in HBM:  Kasa start + LM/Huber refinement (one fused launch,
-pcfit_fit_batch_dev) followed by the residual pass (pcfit_residuals_batch_dev:
-delta-r histogram of 256 bins over +-10 sigma, Rmax / Rmin and their indices).
+already resident in HBM:  Kasa start + LM/Huber refinement (one launch,
+pcfit_fit_batch_dev, the slice held in registers) followed by the residual pass
+(pcfit_residuals_batch_dev: delta-r histogram of 256 bins over +-10 sigma,
+Rmax / Rmin and their indices).
 Workload at N=1: 10 000 slices x 8192 points, FP64, synthetic noisy cylinder
 (the "1x MI355X batched algebraic+geometric fit" configuration).  With N > 1
 every rank owns its own batch of that size (slices shard with no data exchange;
@@ -31,11 +32,13 @@ sys.path.insert(0, ROOT)
 from pointcloud_amd import _ffi as F            # noqa: E402
 from pointcloud_amd.synth import make_slices    # noqa: E402
 
-# how the flop figure of the fused fit kernel is counted (per point and pass): building the
-# normal equations = 2 sqrt-class + 1 divide + 9 weighted sums ~ 70 flop, one cost evaluation
-# = 1 sqrt-class + compare + accumulate ~ 30 flop.  100 literal iterations of both = 1e4 flop/pt.
-FLOP_HG_PASS = 70.0
-FLOP_COST_PASS = 30.0
+# how the flop figure of the fit kernel is counted (per point and sweep): building the normal
+# equations = sqrt + divide (~15 flop each in Newton steps) + Jacobian + 9 weighted sums ~ 70 flop;
+# a candidate sweep adds compare, square and accumulate for the cost ~ 80 flop.  The reference's
+# literal loop does both computations separately in each of its 100 iterations (~1e4 flop/pt).
+FLOP_HG_PASS = 70.0     # sweep that builds the normal equations
+FLOP_COST_PASS = 80.0   # sweep that evaluates a candidate: the same plus the Huber cost
+FLOP_KASA = 20.0        # two passes: means, then seven centred sums
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
@@ -173,10 +176,10 @@ def main():
 
     ms_step = dt / a.steps * 1e3
     fit_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_fit]))
-    res_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_res]))
     it = iters.cpu().numpy().astype(np.float64)
-    flop_launch = float(n * (FLOP_HG_PASS * it[:, 2].sum() + FLOP_COST_PASS * it[:, 3].sum()))
+    flop_launch = float(n * (FLOP_HG_PASS * it[:, 2].sum() + FLOP_COST_PASS * it[:, 3].sum() + FLOP_KASA * S))
     res_bytes = float(S * n * 16)
+    res_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_res]))
 
     if rank == 0:
         traffic = {}
@@ -201,14 +204,17 @@ def main():
                        "slices_per_gpu": S, "points_per_slice": n, "hist_bins": H,
                        "parallelism": f"slice-sharded x{world}" + (", RCCL all-gather of fits+histograms" if world > 1 else "")},
             "roofline": {
-                "kernel": "fit_kernel (Kasa + LM, slice in registers)", "bound": "valu_fp64",
+                "kernel": "fit_kernel<32,256> (Kasa + LM, slice in registers)",
+                "bound": "valu_fp64",
                 "achieved": flop_launch / (fit_ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
                 "frac": flop_launch / (fit_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
                 "traffic": traffic.get("fit_kernel_bytes"),
                 "avg_launch_ms": fit_ms,
                 "flop_per_point": flop_launch / (S * n),
-                "mean_hg_passes": float(it[:, 2].mean()), "mean_cost_passes": float(it[:, 3].mean()),
+                "mean_first_sweeps": float(it[:, 2].mean()), "mean_candidate_sweeps": float(it[:, 3].mean()),
+                "algorithmic_bytes": res_bytes,
                 "algorithmic_hbm_gbs": res_bytes / (fit_ms * 1e-3) / 1e9,
+                "hbm_frac": res_bytes / (fit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             },
             "roofline_hbm": {
                 "kernel": "residuals_kernel", "bound": "hbm",
@@ -217,7 +223,6 @@ def main():
                 "traffic": traffic.get("residuals_kernel_bytes"),
                 "avg_launch_ms": res_ms,
             },
-            "fit_plus_residual_hbm_frac": 2 * res_bytes / ((fit_ms + res_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS,
         }
         if world == 1 and not a.no_cpu_baseline:
             rate, k, secs = cpu_baseline(xh, yh, offh, H, lo, hi)

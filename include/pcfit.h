@@ -101,8 +101,8 @@ int pcfit_kasa_batch_dev(const double *x, const double *y, const int64_t *offset
 
 /* ---- geometric refinement: lm_circle_geometric, circle_fitting.py:57-109 */
 /* init, out: S*3.  iters (nullable): S*4 = {iterations the reference loop
- * runs, accepted steps, passes over the points that built the normal
- * equations, passes that evaluated a candidate's cost}.  max_slice_len:
+ * runs, accepted steps, sweeps over the points that only built the normal
+ * equations, sweeps that evaluated a candidate}.  max_slice_len:
  * largest slice population (lets the launch keep a slice in registers); pass 0
  * if unknown. */
 int pcfit_lm_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
@@ -117,6 +117,16 @@ int pcfit_fit_batch_dev(const double *x, const double *y, const int64_t *offsets
                         int64_t max_slice_len, double huber_delta, int32_t max_iter, double lm_lambda0,
                         double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
                         int32_t *status, void *stream);
+
+/* The same, followed by the residual statistics of pcfit_residuals_batch_dev
+ * about the fitted circle (histogram, Rmax / Rmin and their indices), all in
+ * one launch: 16 bytes of HBM traffic per point for the whole fit + residual
+ * pass.  At most 4096 bins. */
+int pcfit_fit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                  int64_t max_slice_len, double huber_delta, int32_t max_iter, double lm_lambda0,
+                                  double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
+                                  int32_t *status, int32_t n_bins, const double *edges, int64_t *hist,
+                                  double *rmax_rmin, int64_t *argmax_argmin, void *stream);
 
 /* ---- RANSAC: _ransac_circle, circle_fitting.py:112-143 --------------- */
 /* triples: n_tables tables of trials*3 int32 (pcfit_choice3_table), device

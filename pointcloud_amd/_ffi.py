@@ -51,6 +51,8 @@ SIGNATURES = {
     "pcfit_lm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp]),
     "pcfit_fit_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,
                                       _vp]),
+    "pcfit_fit_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
+                                                _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_ransac_workspace_bytes": (_sz, [_i64]),
     "pcfit_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _sz, _vp]),

@@ -10,17 +10,19 @@
 // fixed butterfly + wave order, so results are bitwise reproducible.  Nothing
 // here is a dense contraction: the bound is the FP64 vector rate (sqrt and
 // divide per point and pass), not MFMA and not HBM.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "pcfit_internal.h"
 
 namespace pcfit {
 
-constexpr int FIT_BLOCK = 256;
 
 // A slice as seen by one thread.  PT > 0: register resident (n <= 256*PT).
 // PT == 0: streamed from global memory on every pass.
-template <int PT>
+template <int PT, int FIT_BLOCK>
 struct SliceView {
     const double *xs, *ys;
     int64_t n;
@@ -41,6 +43,25 @@ struct SliceView {
         }
     }
 
+    // f(x, y, slice-local index)
+    template <class F>
+    __device__ __forceinline__ void each_indexed(F &&f) const
+    {
+        if constexpr (PT > 0) {
+#pragma unroll
+            for (int k = 0; k < PT; k++) {
+                const int32_t i = (int32_t)threadIdx.x + k * FIT_BLOCK;
+                if (i < n)
+                    f(rx[k], ry[k], i);
+                if ((k & 3) == 3)
+                    __builtin_amdgcn_sched_barrier(0);      // keep the unrolled bodies from piling up in registers
+            }
+        } else {
+            for (int64_t i = threadIdx.x; i < n; i += FIT_BLOCK)
+                f(xs[i], ys[i], (int32_t)i);
+        }
+    }
+
     template <class F>
     __device__ __forceinline__ void each(F &&f) const
     {
@@ -57,8 +78,8 @@ struct SliceView {
 };
 
 // circle_fitting.py:35-54.  Uniform result in every thread.
-template <int PT>
-__device__ int kasa_slice(const SliceView<PT> &P, double *lds, double out[3])
+template <int PT, int FIT_BLOCK>
+__device__ __forceinline__ int kasa_slice(const SliceView<PT, FIT_BLOCK> &P, double *lds, double out[3])
 {
     out[0] = out[1] = out[2] = __longlong_as_double(0x7ff8000000000000ll);
     if (P.n < 3)
@@ -77,11 +98,11 @@ __device__ int kasa_slice(const SliceView<PT> &P, double *lds, double out[3])
         const double uu = u * u, vv = v * v;
         m[0] += uu;
         m[1] += vv;
-        m[2] += u * v;
-        m[3] += uu * u;
-        m[4] += vv * v;
-        m[5] += u * v * v;
-        m[6] += v * u * u;
+        m[2] = fma(u, v, m[2]);
+        m[3] = fma(uu, u, m[3]);
+        m[4] = fma(vv, v, m[4]);
+        m[5] = fma(u, vv, m[5]);
+        m[6] = fma(v, uu, m[6]);
     });
     block_sum<7>(m, lds);
     const double a = 2 * m[0], b = 2 * m[2], d = 2 * m[1];
@@ -164,58 +185,121 @@ struct LmParams {
     int32_t max_iter;
 };
 
-// circle_fitting.py:80-109.  The reference rebuilds H and g in every iteration;
-// after a rejected step the parameters have not moved, so H and g are the same
-// bits as before and are kept instead.  Once a rejected candidate equals the
-// current parameters bit for bit, every later (more strongly damped) candidate
-// does too and is rejected with the very same cost, so the loop stops there and
-// reports the iteration count the literal loop would have reached.
-template <int PT>
-__device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds, double par[3], int32_t iters[4])
+// 1/sqrt(d) to about one ulp: hardware estimate plus two Newton steps.  Used in
+// the LM passes only, whose results are held to 1e-9, not to the last bit; the
+// inlier tests and every reported radius use IEEE sqrt.
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// smallest value over the workgroup (order independent)
+__device__ __forceinline__ double block_min(double v, double *scratch)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmin(v, __shfl_xor(v, m, WAVE));
+    const int nw = blockDim.x >> 6;
+    if (nw == 1)
+        return v;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+        scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    for (int w = 0; w < nw; w++)
+        v = fmin(v, scratch[w]);
+    return v;
+}
+
+// circle_fitting.py:80-109.  Every accept / reject decision is the reference's
+// (cost of the candidate against the last accepted cost).  Two things the
+// literal loop spends most of its 100 iterations on are not recomputed:
+//  * after a rejected step the parameters have not moved, so H and g are the
+//    same bits as before and are kept; the sweep that evaluates a candidate's
+//    cost also accumulates H and g at the candidate (same distances), so an
+//    accepted step needs no further sweep;
+//  * the loop ends as soon as no later candidate can be accepted.  The Huber
+//    cost F is convex in the residuals and the residual of a point is convex in
+//    the centre, which gives, for a step d from the current parameters p,
+//        F(p + d) >= F(p) + g.d - |d_c|^2 * sum_i |psi(r_i)| / r_i
+//    (psi = Huber influence, r_i the point's distance, valid while
+//    |d_c| <= min_i r_i / 2).  When |g.d| plus that curvature term is below a
+//    quarter of tol_cost the candidate cannot beat the last cost by tol_cost,
+//    and neither can the shorter steps of the stronger damping that would
+//    follow: the remaining iterations are all rejections.  The same holds
+//    when a rejected candidate equals the current parameters bit for bit.
+//    The iteration count the literal loop would have reached is reported.
+template <int PT, int FIT_BLOCK>
+__device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, const LmParams prm, double *lds, double par[3], int32_t iters[4])
 {
     double cx = par[0], cy = par[1], rad = par[2];
-    double lam = prm.lam0, prev = __longlong_as_double(0x7ff0000000000000ll);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double lam = prm.lam0, prev = inf;
     const double delta = prm.delta;
-    double hg[9];   // H00 H01 H02 H11 H12 H22 g0 g1 g2
-    bool fresh = false;
-    int32_t it = 0, acc = 0, n_hg = 0, n_cost = 0;
-    for (; it < prm.max_iter; it++) {
-        if (!fresh) {
-            n_hg++;
+    // One sweep over the points at parameters (px0, py0, pr): the normal equations H, g of the
+    // Huber-weighted problem, the curvature sum and the Huber cost, all from the same distances.
+    //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
+    //   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones
+    // The totals of a sweep stay in LDS (tot, 12 doubles): they are the same for every thread, and
+    // keeping two sets of them in registers would cost 48 VGPRs per lane.
+    auto sweep = [&](double px0, double py0, double pr, double *tot, double &lo_ri) {
+        double acc[12];
 #pragma unroll
-            for (int k = 0; k < 9; k++)
-                hg[k] = 0.0;
-            P.each([&](double px, double py) {
-                const double dx = px - cx, dy = py - cy;
-                const double ri = sqrt(dx * dx + dy * dy) + 1e-16;
-                const double r = ri - rad;
-                const double a = fabs(r);
-                const double inv = 1.0 / ri;
-                double j0 = -dx * inv, j1 = -dy * inv, j2 = -1.0, rw = r;
-                if (a > delta) {
-                    const double sw = sqrt(delta / (a + 1e-16));
-                    j0 *= sw;
-                    j1 *= sw;
-                    j2 = -sw;
-                    rw = r * sw;
-                }
-                hg[0] += j0 * j0;
-                hg[1] += j0 * j1;
-                hg[2] += j0 * j2;
-                hg[3] += j1 * j1;
-                hg[4] += j1 * j2;
-                hg[5] += j2 * j2;
-                hg[6] += j0 * rw;
-                hg[7] += j1 * rw;
-                hg[8] += j2 * rw;
-            });
-            block_sum<9>(hg, lds);
-            fresh = true;
-        }
+        for (int k = 0; k < 12; k++)
+            acc[k] = 0.0;
+        double low = inf;
+        P.each([&](double px, double py) {
+            const double dx = px - px0, dy = py - py0;
+            const double d2 = fma(dx, dx, dy * dy);
+            // ri = sqrt(d2) + 1e-16 and 1/ri (first order in the 1e-16)
+            const double y0 = d2 > 0.0 ? rsqrt_nr(d2) : 0.0;
+            const double ri = fma(d2, y0, 1e-16);
+            const double inv = d2 > 0.0 ? fma(-1e-16 * y0, y0, y0) : 1e16;
+            const double r = ri - pr;
+            const double a = fabs(r);
+            double j0 = -dx * inv, j1 = -dy * inv, j2 = -1.0, rw = r;
+            double psi = a;
+            if (a > delta) {
+                const double sw = sqrt(delta / (a + 1e-16));
+                j0 *= sw;
+                j1 *= sw;
+                j2 = -sw;
+                rw = r * sw;
+                psi = delta;
+                acc[11] = fma(delta, a - 0.5 * delta, acc[11]);
+            } else {
+                acc[10] = fma(a, a, acc[10]);
+            }
+            acc[0] = fma(j0, j0, acc[0]);
+            acc[1] = fma(j0, j1, acc[1]);
+            acc[2] = fma(j0, j2, acc[2]);
+            acc[3] = fma(j1, j1, acc[3]);
+            acc[4] = fma(j1, j2, acc[4]);
+            acc[5] = fma(j2, j2, acc[5]);
+            acc[6] = fma(j0, rw, acc[6]);
+            acc[7] = fma(j1, rw, acc[7]);
+            acc[8] = fma(j2, rw, acc[8]);
+            acc[9] = fma(psi, inv, acc[9]);
+            low = fmin(low, ri);
+        });
+        block_sum_to_lds<12>(acc, lds, tot);
+        lo_ri = block_min(low, lds);
+    };
+
+    double *hg = lds + 12 * 16, *trial = lds + 12 * 16 + 12;      // LDS: current and candidate totals
+    double min_ri, trial_min;
+    sweep(cx, cy, rad, hg, min_ri);            // H and g at the start; its cost is not used (cost_prev = inf)
+    int32_t it = 0, acc_steps = 0, n_first = 1, n_sweeps = 0;
+    for (; it < prm.max_iter; it++) {
+        const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
         double A[3][3] = {{hg[0] + lam * hg[0], hg[1], hg[2]},
                           {hg[1], hg[3] + lam * hg[3], hg[4]},
                           {hg[2], hg[4], hg[5] + lam * hg[5]}};
-        double b[3] = {hg[6], hg[7], hg[8]}, step[3];
+        double b[3] = {g0, g1, g2}, step[3];
         if (!solve3x3(A, b, step)) {
             lam *= 3;
             continue;
@@ -223,30 +307,34 @@ __device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds
         step[0] = -step[0];
         step[1] = -step[1];
         step[2] = -step[2];
+        if (prev < inf) {
+            const double gd = fabs(g0 * step[0] + g1 * step[1] + g2 * step[2]);
+            const double dc2 = step[0] * step[0] + step[1] * step[1];
+            if (gd + hg[9] * dc2 < 0.25 * prm.tol_cost && 4.0 * dc2 <= min_ri * min_ri) {
+                it = prm.max_iter;               // nothing from here on can be accepted
+                break;
+            }
+        }
         const double tx = cx + step[0], ty = cy + step[1];
         double tr = rad + step[2];
         if (!(tr > 1e-12))
             tr = 1e-12;
-        n_cost++;
-        double c2[2] = {0.0, 0.0};   // quadratic part, linear part
-        P.each([&](double px, double py) {
-            const double dx = px - tx, dy = py - ty;
-            const double a = fabs((sqrt(dx * dx + dy * dy) + 1e-16) - tr);
-            if (a <= delta)
-                c2[0] += a * a;
-            else
-                c2[1] += delta * (a - 0.5 * delta);
-        });
-        block_sum<2>(c2, lds);
-        const double cost = 0.5 * c2[0] + c2[1];
+        // the candidate's cost, and in the same sweep the H and g the next iteration needs if it is accepted
+        n_sweeps++;
+        sweep(tx, ty, tr, trial, trial_min);
+        const double cost = 0.5 * trial[10] + trial[11];
         if (cost < prev - prm.tol_cost) {
             cx = tx;
             cy = ty;
             rad = tr;
             prev = cost;
             lam = lam / 3 > 1e-12 ? lam / 3 : 1e-12;
-            fresh = false;
-            acc++;
+            __syncthreads();                     // everyone has read trial[10..11] and the old hg
+            if (threadIdx.x < 10)
+                hg[threadIdx.x] = trial[threadIdx.x];
+            __syncthreads();
+            min_ri = trial_min;
+            acc_steps++;
             if (sqrt(step[0] * step[0] + step[1] * step[1] + step[2] * step[2]) < prm.tol_update) {
                 it++;
                 break;
@@ -262,21 +350,21 @@ __device__ void lm_slice(const SliceView<PT> &P, const LmParams prm, double *lds
     par[0] = cx;
     par[1] = cy;
     par[2] = rad;
-    iters[0] = it;        // iterations of the literal loop
-    iters[1] = acc;       // accepted steps
-    iters[2] = n_hg;      // passes over the points that built H and g
-    iters[3] = n_cost;    // passes over the points that evaluated a candidate's cost
+    iters[0] = it;          // iterations the literal loop runs
+    iters[1] = acc_steps;   // accepted steps
+    iters[2] = n_first;     // sweeps that only built H and g (the first)
+    iters[3] = n_sweeps;    // sweeps that evaluated a candidate (cost, and H and g for the next step)
 }
 
-template <int PT>
-__global__ __launch_bounds__(FIT_BLOCK) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                         const int64_t *__restrict__ offsets, double *__restrict__ out,
                                                         int32_t *__restrict__ status)
 {
-    __shared__ double lds[9 * 16];
+    __shared__ double lds[12 * 16 + 24];
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT> P;
+    SliceView<PT, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3];
     const int st = kasa_slice(P, lds, c);
@@ -289,16 +377,16 @@ __global__ __launch_bounds__(FIT_BLOCK) void kasa_kernel(const double *__restric
     }
 }
 
-template <int PT>
-__global__ __launch_bounds__(FIT_BLOCK) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                       const int64_t *__restrict__ offsets,
                                                       const double *__restrict__ init, LmParams prm,
                                                       double *__restrict__ out, int32_t *__restrict__ iters)
 {
-    __shared__ double lds[9 * 16];
+    __shared__ double lds[12 * 16 + 24];
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT> P;
+    SliceView<PT, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3] = {init[3 * s], init[3 * s + 1], init[3 * s + 2]};
     int32_t it[4] = {0, 0, 0, 0};
@@ -317,16 +405,16 @@ __global__ __launch_bounds__(FIT_BLOCK) void lm_kernel(const double *__restrict_
 
 // Kasa start, then LM, the slice read once.  status follows the Kasa fit; slices
 // whose Kasa fit is unavailable (n < 3) get NaN.
-template <int PT>
-__global__ __launch_bounds__(FIT_BLOCK) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const int64_t *__restrict__ offsets, LmParams prm,
                                                        double *__restrict__ kasa_out, double *__restrict__ out,
                                                        int32_t *__restrict__ iters, int32_t *__restrict__ status)
 {
-    __shared__ double lds[9 * 16];
+    __shared__ double lds[12 * 16 + 24];
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT> P;
+    SliceView<PT, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3];
     const int st = kasa_slice(P, lds, c);
@@ -352,29 +440,168 @@ __global__ __launch_bounds__(FIT_BLOCK) void fit_kernel(const double *__restrict
     }
 }
 
-// register budget: PT points per thread cost 4*PT VGPRs
-static int pick_pt(int64_t max_len)
+struct Extreme2 {
+    double r;
+    int32_t i;
+};
+__device__ __forceinline__ Extreme2 better_max(Extreme2 a, Extreme2 b)
 {
-    if (max_len <= 0) return 0;
-    if (max_len <= 1 * FIT_BLOCK) return 1;
-    if (max_len <= 4 * FIT_BLOCK) return 4;
-    if (max_len <= 8 * FIT_BLOCK) return 8;
-    if (max_len <= 16 * FIT_BLOCK) return 16;
-    if (max_len <= 32 * FIT_BLOCK) return 32;
-    return 0;
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    return (b.r > a.r || (b.r == a.r && b.i < a.i)) ? b : a;
+}
+__device__ __forceinline__ Extreme2 better_min(Extreme2 a, Extreme2 b)
+{
+    if (b.i < 0) return a;
+    if (a.i < 0) return b;
+    return (b.r < a.r || (b.r == a.r && b.i < a.i)) ? b : a;
 }
 
-// calls f(std::integral_constant<int, PT>) for the points-per-thread class
-template <class F>
-static void dispatch_pt(int pt, F &&f)
+// Kasa -> LM -> residual statistics with the slice read from HBM once:
+// histogram of dr = hypot - R (numpy.histogram rules, H bins, edges given),
+// Rmax / Rmin and the first index attaining each (analyzer.py:83-92,
+// gui.py:979-983).  Dynamic LDS: (H+1) doubles of edges, then H int32 counters.
+template <int PT, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void fit_residual_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
+    double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
+    int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
+    double *__restrict__ rmax_rmin, int64_t *__restrict__ argmax_argmin)
 {
-    switch (pt) {
-    case 1: f(std::integral_constant<int, 1>{}); break;
-    case 4: f(std::integral_constant<int, 4>{}); break;
-    case 8: f(std::integral_constant<int, 8>{}); break;
-    case 16: f(std::integral_constant<int, 16>{}); break;
-    case 32: f(std::integral_constant<int, 32>{}); break;
-    default: f(std::integral_constant<int, 0>{}); break;
+    extern __shared__ double lds_dyn[];
+    __shared__ double lds[12 * 16 + 24];
+    __shared__ Extreme2 wmax[FIT_BLOCK / WAVE], wmin[FIT_BLOCK / WAVE];
+    double *ledge = lds_dyn;
+    int32_t *lhist = reinterpret_cast<int32_t *>(lds_dyn + (H > 0 ? H + 1 : 0));
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], n = offsets[s + 1] - off;
+    SliceView<PT, FIT_BLOCK> P;
+    P.load(x, y, off, n);
+    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
+        lhist[b] = 0;
+    for (int b = threadIdx.x; b <= H && H > 0; b += FIT_BLOCK)
+        ledge[b] = edges[b];
+    double c[3];
+    const int st = kasa_slice(P, lds, c);
+    if (threadIdx.x == 0 && kasa_out) {
+        kasa_out[3 * s] = c[0];
+        kasa_out[3 * s + 1] = c[1];
+        kasa_out[3 * s + 2] = c[2];
+    }
+    int32_t it[4] = {0, 0, 0, 0};
+    if (st != PCFIT_ST_SPARSE)
+        lm_slice(P, prm, lds, c, it);
+    __syncthreads();
+    const double cx = c[0], cy = c[1], R = c[2];
+    const double e0 = H > 0 ? ledge[0] : 0.0, eH = H > 0 ? ledge[H] : 0.0;
+    // numpy.histogram puts d into the bin b with edges[b] <= d < edges[b+1] (last bin closed): it
+    // guesses b by scaling and repairs the guess against the edges.  Any guess within one bin of the
+    // truth gives the same b, so the guess here multiplies by H / span instead of dividing.
+    const double scale = (double)H / (eH - e0);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    Extreme2 mx{-inf, -1}, mn{inf, -1};
+    P.each_indexed([&](double px, double py, int32_t i) {
+        const double r = cr_hypot(px - cx, py - cy);
+        const double d = r - R;
+        if (r > mx.r) { mx.r = r; mx.i = i; }          // strict: the first index of an extreme value stays
+        if (r < mn.r) { mn.r = r; mn.i = i; }
+        if (H > 0 && d >= e0 && d <= eH) {
+            // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
+            int32_t b = (int32_t)((d - e0) * scale);
+            b = b < 0 ? 0 : (b > H - 1 ? H - 1 : b);
+            while (b > 0 && d < lds_dyn[b]) b--;
+            while (b < H - 1 && d >= lds_dyn[b + 1]) b++;
+            atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + H + 1) + b, 1);
+        }
+    });
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        Extreme2 o;
+        o.r = __shfl_xor(mx.r, m, WAVE);
+        o.i = __shfl_xor(mx.i, m, WAVE);
+        mx = better_max(mx, o);
+        o.r = __shfl_xor(mn.r, m, WAVE);
+        o.i = __shfl_xor(mn.i, m, WAVE);
+        mn = better_min(mn, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wmax[threadIdx.x >> 6] = mx;
+        wmin[threadIdx.x >> 6] = mn;
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
+        hist[s * H + b] = (int64_t)lhist[b];
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < FIT_BLOCK / WAVE; w++) {
+            mx = better_max(mx, wmax[w]);
+            mn = better_min(mn, wmin[w]);
+        }
+        rmax_rmin[2 * s] = mx.r;
+        rmax_rmin[2 * s + 1] = mn.r;
+        argmax_argmin[2 * s] = mx.i;
+        argmax_argmin[2 * s + 1] = mn.i;
+        out[3 * s] = cx;
+        out[3 * s + 1] = cy;
+        out[3 * s + 2] = R;
+        if (iters) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                iters[4 * s + k] = it[k];
+        }
+        if (status)
+            status[s] = st;
+    }
+}
+
+// Launch shape for a batch whose longest slice has max_len points: threads per
+// workgroup x points per thread (4 VGPRs each).  0 points per thread = stream
+// the slice from global memory on every pass.
+struct FitShape {
+    int block, pt;
+};
+
+static FitShape pick_shape(int64_t max_len)
+{
+    if (max_len <= 0) return {256, 0};
+    if (max_len <= 64) return {64, 1};
+    if (max_len <= 256) return {256, 1};
+    if (max_len <= 1024) return {256, 4};
+    if (max_len <= 2048) return {256, 8};
+    if (max_len <= 4096) return {512, 8};
+    if (max_len <= 8192) {
+        static const FitShape big = [] {
+            // measured on MI355X, 10 000 slices x 8192 points: 256x32 beats 512x16 and 1024x8 (fewer waves
+            // to reduce over, more independent points per lane); the variable is a tuning knob
+            const char *e = getenv("PCFIT_FIT_SHAPE");
+            if (e && !strcmp(e, "512x16")) return FitShape{512, 16};
+            if (e && !strcmp(e, "1024x8")) return FitShape{1024, 8};
+            return FitShape{256, 32};
+        }();
+        return big;
+    }
+    return {256, 0};
+}
+
+template <int B, int P>
+struct ShapeTag {
+    static constexpr int block = B, pt = P;
+};
+
+// calls f(ShapeTag<block, pt>)
+template <class F>
+static void dispatch_shape(FitShape sh, F &&f)
+{
+    const int key = sh.block * 100 + sh.pt;
+    switch (key) {
+    case 64 * 100 + 1: f(ShapeTag<64, 1>{}); break;
+    case 256 * 100 + 1: f(ShapeTag<256, 1>{}); break;
+    case 256 * 100 + 4: f(ShapeTag<256, 4>{}); break;
+    case 256 * 100 + 8: f(ShapeTag<256, 8>{}); break;
+    case 512 * 100 + 8: f(ShapeTag<512, 8>{}); break;
+    case 256 * 100 + 32: f(ShapeTag<256, 32>{}); break;
+    case 512 * 100 + 16: f(ShapeTag<512, 16>{}); break;
+    case 1024 * 100 + 8: f(ShapeTag<1024, 8>{}); break;
+    default: f(ShapeTag<256, 0>{}); break;
     }
 }
 
@@ -382,8 +609,9 @@ int launch_kasa(const double *x, const double *y, const int64_t *offsets, int64_
                 int32_t *status, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
-    dispatch_pt(pick_pt(max_len), [&](auto pt) {
-        kasa_kernel<decltype(pt)::value><<<dim3((unsigned)S), dim3(FIT_BLOCK), 0, st>>>(x, y, offsets, out, status);
+    dispatch_shape(pick_shape(max_len), [&](auto t) {
+        using T = decltype(t);
+        kasa_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, out, status);
     });
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
@@ -393,9 +621,9 @@ int launch_lm(const double *x, const double *y, const int64_t *offsets, int64_t 
               const double *init, const LmParams &prm, double *out, int32_t *iters, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
-    dispatch_pt(pick_pt(max_len), [&](auto pt) {
-        lm_kernel<decltype(pt)::value><<<dim3((unsigned)S), dim3(FIT_BLOCK), 0, st>>>(x, y, offsets, init, prm, out,
-                                                                                      iters);
+    dispatch_shape(pick_shape(max_len), [&](auto t) {
+        using T = decltype(t);
+        lm_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, init, prm, out, iters);
     });
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
@@ -405,9 +633,25 @@ int launch_fit(const double *x, const double *y, const int64_t *offsets, int64_t
                const LmParams &prm, double *kasa_out, double *out, int32_t *iters, int32_t *status, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
-    dispatch_pt(pick_pt(max_len), [&](auto pt) {
-        fit_kernel<decltype(pt)::value><<<dim3((unsigned)S), dim3(FIT_BLOCK), 0, st>>>(x, y, offsets, prm, kasa_out,
-                                                                                       out, iters, status);
+    dispatch_shape(pick_shape(max_len), [&](auto t) {
+        using T = decltype(t);
+        fit_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, prm, kasa_out, out,
+                                                                                  iters, status);
+    });
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+int launch_fit_residual(const double *x, const double *y, const int64_t *offsets, int64_t S, int64_t max_len,
+                        const LmParams &prm, double *kasa_out, double *out, int32_t *iters, int32_t *status, int32_t H,
+                        const double *edges, int64_t *hist, double *rmm, int64_t *amm, hipStream_t st)
+{
+    if (S == 0) return PCFIT_OK;
+    const size_t lds = H > 0 ? (size_t)(H + 1) * 8 + (size_t)H * 4 : 0;
+    dispatch_shape(pick_shape(max_len), [&](auto t) {
+        using T = decltype(t);
+        fit_residual_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), lds, st>>>(
+            x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
     });
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
@@ -447,4 +691,22 @@ PCFIT_API int pcfit_fit_batch_dev(const double *x, const double *y, const int64_
     PCFIT_REQUIRE(max_iter >= 0, "fit: max_iter negative");
     LmParams prm{huber_delta, lm_lambda0, tol_update, tol_cost, max_iter};
     return launch_fit(x, y, offsets, n_slices, max_slice_len, prm, kasa_out, out, iters, status, as_stream(stream));
+}
+
+PCFIT_API int pcfit_fit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets,
+                                            int64_t n_slices, int64_t max_slice_len, double huber_delta,
+                                            int32_t max_iter, double lm_lambda0, double tol_update, double tol_cost,
+                                            double *kasa_out, double *out, int32_t *iters, int32_t *status,
+                                            int32_t n_bins, const double *edges, int64_t *hist, double *rmax_rmin,
+                                            int64_t *argmax_argmin, void *stream)
+{
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "fit_residuals: n_slices out of range");
+    PCFIT_REQUIRE(n_bins >= 0 && n_bins <= 4096, "fit_residuals: n_bins must be 0..4096");
+    PCFIT_REQUIRE(n_slices == 0 || (x && y && offsets && out && rmax_rmin && argmax_argmin),
+                  "fit_residuals: null pointer");
+    PCFIT_REQUIRE(n_bins == 0 || (edges && hist), "fit_residuals: histogram asked for without edges/hist");
+    PCFIT_REQUIRE(max_iter >= 0, "fit_residuals: max_iter negative");
+    LmParams prm{huber_delta, lm_lambda0, tol_update, tol_cost, max_iter};
+    return launch_fit_residual(x, y, offsets, n_slices, max_slice_len, prm, kasa_out, out, iters, status, n_bins,
+                               edges, hist, rmax_rmin, argmax_argmin, as_stream(stream));
 }

@@ -131,6 +131,31 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *scratch)
     }
 }
 
+// Same sum, but the K totals are left in LDS (dst, K doubles) instead of in
+// every thread's registers; callers read what they need after the call.
+template <int K>
+__device__ __forceinline__ void block_sum_to_lds(double (&v)[K], double *scratch, double *dst)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        v[k] = wave_sum(v[k]);
+    __syncthreads();                       // scratch / dst may still be read from a previous call
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            scratch[k * 16 + wave] = v[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double s = scratch[threadIdx.x * 16];
+        for (int w = 1; w < nw; w++)
+            s += scratch[threadIdx.x * 16 + w];
+        dst[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
 // (theta, r) as the reference forms them: theta = (atan2(dy,dx) + 2pi) mod 2pi
 __device__ __forceinline__ double wrap_angle(double dy, double dx)
 {

@@ -3,6 +3,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first, so that the process runs on ONE HIP runtime: the one torch ships)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -381,6 +381,38 @@ def test_full_size_fit_residual_pass():
                                                                     res["rmax"][s], res["rmin"][s])
 
 
+def test_fused_fit_residual_launch_equals_the_separate_kernels():
+    import ctypes as C
+    import torch
+    x, y, off = R.make_slices(300, 4000, seed=4, outlier_frac=0.1, jitter=0.05)
+    off = off.copy()
+    off[1:] -= np.arange(300) % 7                      # ragged
+    off[-1] = off[-2] + 2                             # a two-point slice at the end
+    x, y = x[:off[-1]], y[:off[-1]]
+    S, H = 300, 128
+    k, st = F.kasa_batch(x, y, off)
+    fit, it = F.lm_batch(x, y, off, k)
+    res = F.residuals_batch(x, y, off, fit, bins=H, lo=-0.4, hi=0.6, want_theta=False, want_dr=False)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dx, dy, doff, dedge = t(x), t(y), t(off), t(np.linspace(-0.4, 0.6, H + 1))
+    ok_, of_ = torch.empty(S, 3, dtype=torch.float64, device=dev), torch.empty(S, 3, dtype=torch.float64, device=dev)
+    oi, os_ = torch.empty(S, 4, dtype=torch.int32, device=dev), torch.empty(S, dtype=torch.int32, device=dev)
+    oh = torch.empty(S, H, dtype=torch.int64, device=dev)
+    orm, oam = torch.empty(S, 2, dtype=torch.float64, device=dev), torch.empty(S, 2, dtype=torch.int64, device=dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, int(np.diff(off).max()), 1.0, 100, 1e-2,
+                                                  1e-10, 1e-12, p(ok_), p(of_), p(oi), p(os_), H, p(dedge), p(oh),
+                                                  p(orm), p(oam), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(ok_.cpu().numpy()[:-1], k[:-1]) and np.array_equal(os_.cpu().numpy(), st)
+    assert np.array_equal(of_.cpu().numpy()[:-1], fit[:-1]) and np.array_equal(oi.cpu().numpy()[:-1], it[:-1])
+    assert np.array_equal(oh.cpu().numpy()[:-1], res["hist"][:-1])
+    assert np.array_equal(oam.cpu().numpy()[:-1, 0], res["argmax"][:-1])
+    assert np.array_equal(orm.cpu().numpy()[:-1, 1], res["rmin"][:-1])
+    assert st[-1] == 1 and np.all(np.isnan(of_.cpu().numpy()[-1]))
+
+
 def test_full_size_ransac_30pct_outliers():
     """10 000 slices x 8192 points, 30 % outliers, 1024 hypotheses: bit-exact consensus on 24 replayed slices."""
     S, n = 10_000, 8192

@@ -1,0 +1,34 @@
+"""Timing harness for the fit kernels (experiments; not part of the bench contract)."""
+import ctypes as C, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloud_amd import _ffi as F
+from pointcloud_amd.synth import make_slices
+
+S, n, H = int(os.environ.get("S", 10000)), int(os.environ.get("NP", 8192)), 256
+dev = torch.device("cuda", 0)
+xh, yh, offh = make_slices(S, n, seed=1, jitter=0.02)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+x, y, off, edges = t(xh), t(yh), t(offh), t(np.linspace(-0.5, 0.5, H + 1))
+kasa = torch.empty(S, 3, dtype=torch.float64, device=dev); fit = torch.empty_like(kasa)
+iters = torch.empty(S, 4, dtype=torch.int32, device=dev); status = torch.empty(S, dtype=torch.int32, device=dev)
+hist = torch.empty(S, H, dtype=torch.int64, device=dev); rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
+amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
+p = lambda a: C.c_void_p(a.data_ptr())
+L = F.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+def timeit(name, fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:28s} {e0.elapsed_time(e1)/reps:8.3f} ms")
+
+timeit("kasa", lambda: F.check(L.pcfit_kasa_batch_dev(p(x), p(y), p(off), S, n, p(kasa), p(status), st)))
+timeit("lm", lambda: F.check(L.pcfit_lm_batch_dev(p(x), p(y), p(off), S, n, p(kasa), 1.0, 100, 1e-2, 1e-10, 1e-12, p(fit), p(iters), st)))
+timeit("fit (kasa+lm)", lambda: F.check(L.pcfit_fit_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), st)))
+timeit("residuals", lambda: F.check(L.pcfit_residuals_batch_dev(p(x), p(y), p(off), S, p(fit), None, None, None, H, p(edges), p(hist), p(rmm), p(amm), st)))
+timeit("fit+residuals fused", lambda: F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st)))
+timeit("fused, no histogram", lambda: F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), 0, None, None, p(rmm), p(amm), st)))
+print("iters", iters[:2].tolist())
