@@ -185,18 +185,6 @@ struct LmParams {
     int32_t max_iter;
 };
 
-// 1/sqrt(d) to about one ulp: hardware estimate plus two Newton steps.  Used in
-// the LM passes only, whose results are held to 1e-9, not to the last bit; the
-// inlier tests and every reported radius use IEEE sqrt.
-__device__ __forceinline__ double rsqrt_nr(double d)
-{
-    double y = __builtin_amdgcn_rsq(d);
-    double h = 0.5 * d;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
-
 // smallest value over the workgroup (order independent)
 __device__ __forceinline__ double block_min(double v, double *scratch)
 {
@@ -240,6 +228,7 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     double lam = prm.lam0, prev = inf;
     const double delta = prm.delta;
+    const double root_delta = sqrt(delta);
     // One sweep over the points at parameters (px0, py0, pr): the normal equations H, g of the
     // Huber-weighted problem, the curvature sum and the Huber cost, all from the same distances.
     //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
@@ -264,7 +253,7 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
             double j0 = -dx * inv, j1 = -dy * inv, j2 = -1.0, rw = r;
             double psi = a;
             if (a > delta) {
-                const double sw = sqrt(delta / (a + 1e-16));
+                const double sw = root_delta * rsqrt_nr(a + 1e-16);      // sqrt(delta / (a + 1e-16))
                 j0 *= sw;
                 j1 *= sw;
                 j2 = -sw;
@@ -291,61 +280,86 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
     };
 
     double *hg = lds + 12 * 16, *trial = lds + 12 * 16 + 12;      // LDS: current and candidate totals
-    double min_ri, trial_min;
-    sweep(cx, cy, rad, hg, min_ri);            // H and g at the start; its cost is not used (cost_prev = inf)
-    int32_t it = 0, acc_steps = 0, n_first = 1, n_sweeps = 0;
-    for (; it < prm.max_iter; it++) {
-        const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
-        double A[3][3] = {{hg[0] + lam * hg[0], hg[1], hg[2]},
-                          {hg[1], hg[3] + lam * hg[3], hg[4]},
-                          {hg[2], hg[4], hg[5] + lam * hg[5]}};
-        double b[3] = {g0, g1, g2}, step[3];
-        if (!solve3x3(A, b, step)) {
-            lam *= 3;
-            continue;
-        }
-        step[0] = -step[0];
-        step[1] = -step[1];
-        step[2] = -step[2];
-        if (prev < inf) {
-            const double gd = fabs(g0 * step[0] + g1 * step[1] + g2 * step[2]);
-            const double dc2 = step[0] * step[0] + step[1] * step[1];
-            if (gd + hg[9] * dc2 < 0.25 * prm.tol_cost && 4.0 * dc2 <= min_ri * min_ri) {
-                it = prm.max_iter;               // nothing from here on can be accepted
-                break;
+    double min_ri = 0.0, trial_min;
+    double tx = cx, ty = cy, tr = rad;          // what the next sweep evaluates: first the start itself
+    double step[3] = {0.0, 0.0, 0.0};
+    bool first = true;
+    int32_t it = 0, acc_steps = 0, n_first = 0, n_sweeps = 0;
+    // (one call site for the sweep: its unrolled body is the bulk of the kernel's code)
+    while (prm.max_iter > 0) {
+        sweep(tx, ty, tr, trial, trial_min);
+        bool adopt, done = false;
+        if (first) {
+            // H and g at the start; its cost is not used (the reference starts from cost_prev = inf)
+            first = false;
+            adopt = true;
+            n_first++;
+        } else {
+            n_sweeps++;
+            const double cost = 0.5 * trial[10] + trial[11];
+            if (cost < prev - prm.tol_cost) {
+                cx = tx;
+                cy = ty;
+                rad = tr;
+                prev = cost;
+                lam = lam / 3 > 1e-12 ? lam / 3 : 1e-12;
+                acc_steps++;
+                adopt = true;
+                it++;
+                done = sqrt(step[0] * step[0] + step[1] * step[1] + step[2] * step[2]) < prm.tol_update;
+            } else {
+                lam *= 3;
+                adopt = false;
+                it++;
+                if (tx == cx && ty == cy && tr == rad) {
+                    it = prm.max_iter;           // every later candidate is this one again
+                    done = true;
+                }
             }
         }
-        const double tx = cx + step[0], ty = cy + step[1];
-        double tr = rad + step[2];
-        if (!(tr > 1e-12))
-            tr = 1e-12;
-        // the candidate's cost, and in the same sweep the H and g the next iteration needs if it is accepted
-        n_sweeps++;
-        sweep(tx, ty, tr, trial, trial_min);
-        const double cost = 0.5 * trial[10] + trial[11];
-        if (cost < prev - prm.tol_cost) {
-            cx = tx;
-            cy = ty;
-            rad = tr;
-            prev = cost;
-            lam = lam / 3 > 1e-12 ? lam / 3 : 1e-12;
-            __syncthreads();                     // everyone has read trial[10..11] and the old hg
+        if (adopt) {
+            __syncthreads();                     // everyone has read trial[10..11] and the old totals
             if (threadIdx.x < 10)
                 hg[threadIdx.x] = trial[threadIdx.x];
             __syncthreads();
             min_ri = trial_min;
-            acc_steps++;
-            if (sqrt(step[0] * step[0] + step[1] * step[1] + step[2] * step[2]) < prm.tol_update) {
-                it++;
-                break;
-            }
-        } else {
-            lam *= 3;
-            if (tx == cx && ty == cy && tr == rad) {
-                it = prm.max_iter;
-                break;
-            }
         }
+        if (done)
+            break;
+        // next candidate from the current H, g (a singular damped system costs an iteration, as in the reference)
+        bool have = false;
+        while (it < prm.max_iter) {
+            const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
+            double A[3][3] = {{hg[0] + lam * hg[0], hg[1], hg[2]},
+                              {hg[1], hg[3] + lam * hg[3], hg[4]},
+                              {hg[2], hg[4], hg[5] + lam * hg[5]}};
+            double b[3] = {g0, g1, g2};
+            if (!solve3x3(A, b, step)) {
+                lam *= 3;
+                it++;
+                continue;
+            }
+            step[0] = -step[0];
+            step[1] = -step[1];
+            step[2] = -step[2];
+            if (prev < inf) {
+                const double gd = fabs(g0 * step[0] + g1 * step[1] + g2 * step[2]);
+                const double dc2 = step[0] * step[0] + step[1] * step[1];
+                if (gd + hg[9] * dc2 < 0.25 * prm.tol_cost && 4.0 * dc2 <= min_ri * min_ri) {
+                    it = prm.max_iter;           // nothing from here on can be accepted
+                    break;
+                }
+            }
+            tx = cx + step[0];
+            ty = cy + step[1];
+            tr = rad + step[2];
+            if (!(tr > 1e-12))
+                tr = 1e-12;
+            have = true;
+            break;
+        }
+        if (!have)
+            break;
     }
     par[0] = cx;
     par[1] = cy;
@@ -357,7 +371,7 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
 }
 
 template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                         const int64_t *__restrict__ offsets, double *__restrict__ out,
                                                         int32_t *__restrict__ status)
 {
@@ -378,7 +392,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void kasa_k
 }
 
 template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                       const int64_t *__restrict__ offsets,
                                                       const double *__restrict__ init, LmParams prm,
                                                       double *__restrict__ out, int32_t *__restrict__ iters)
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void lm_ker
 // Kasa start, then LM, the slice read once.  status follows the Kasa fit; slices
 // whose Kasa fit is unavailable (n < 3) get NaN.
 template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const int64_t *__restrict__ offsets, LmParams prm,
                                                        double *__restrict__ kasa_out, double *__restrict__ out,
                                                        int32_t *__restrict__ iters, int32_t *__restrict__ status)
@@ -462,7 +476,7 @@ __device__ __forceinline__ Extreme2 better_min(Extreme2 a, Extreme2 b)
 // Rmax / Rmin and the first index attaining each (analyzer.py:83-92,
 // gui.py:979-983).  Dynamic LDS: (H+1) doubles of edges, then H int32 counters.
 template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void fit_residual_kernel(
+__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void fit_residual_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
     double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
     int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
@@ -508,9 +522,9 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : 2)) void fit_re
         if (H > 0 && d >= e0 && d <= eH) {
             // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
             int32_t b = (int32_t)((d - e0) * scale);
-            b = b < 0 ? 0 : (b > H - 1 ? H - 1 : b);
-            while (b > 0 && d < lds_dyn[b]) b--;
-            while (b < H - 1 && d >= lds_dyn[b + 1]) b++;
+            b = b > H - 1 ? H - 1 : b;
+            if (d < lds_dyn[b]) b--;
+            else if (b < H - 1 && d >= lds_dyn[b + 1]) b++;
             atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + H + 1) + b, 1);
         }
     });
@@ -574,6 +588,8 @@ static FitShape pick_shape(int64_t max_len)
             // to reduce over, more independent points per lane); the variable is a tuning knob
             const char *e = getenv("PCFIT_FIT_SHAPE");
             if (e && !strcmp(e, "512x16")) return FitShape{512, 16};
+            if (e && !strcmp(e, "384x22")) return FitShape{384, 22};
+            if (e && !strcmp(e, "320x26")) return FitShape{320, 26};
             if (e && !strcmp(e, "1024x8")) return FitShape{1024, 8};
             return FitShape{256, 32};
         }();
@@ -600,6 +616,8 @@ static void dispatch_shape(FitShape sh, F &&f)
     case 512 * 100 + 8: f(ShapeTag<512, 8>{}); break;
     case 256 * 100 + 32: f(ShapeTag<256, 32>{}); break;
     case 512 * 100 + 16: f(ShapeTag<512, 16>{}); break;
+    case 384 * 100 + 22: f(ShapeTag<384, 22>{}); break;
+    case 320 * 100 + 26: f(ShapeTag<320, 26>{}); break;
     case 1024 * 100 + 8: f(ShapeTag<1024, 8>{}); break;
     default: f(ShapeTag<256, 0>{}); break;
     }

@@ -162,9 +162,22 @@ __device__ __forceinline__ double wrap_angle(double dy, double dx)
     return fmod(atan2(dy, dx) + TWO_PI, TWO_PI);
 }
 
-// hypot(x, y) rounded to nearest: sqrt of the double-double sum of squares, then
-// one Newton correction with the residual taken exactly.  No range scaling:
-// meant for |x|, |y| within [1e-140, 1e140].
+// 1/sqrt(d) to about one ulp: hardware estimate plus two Newton steps (d > 0, normal range)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// hypot(x, y) rounded to nearest.  The sum of squares is formed exactly as a
+// double-double (s + tail); r0 ~ sqrt(s) comes from the reciprocal square root
+// and one Newton step with the residual s + tail - r0^2 taken exactly lands on
+// the correctly rounded value (the step's own error is ~1e-32 relative, so only
+// a result within that distance of a rounding tie could differ).  No range
+// scaling: meant for |x|, |y| within [1e-140, 1e140].
 __device__ __forceinline__ double cr_hypot(double x, double y)
 {
     const double p1 = x * x, e1 = fma(x, x, -p1);
@@ -173,12 +186,13 @@ __device__ __forceinline__ double cr_hypot(double x, double y)
     const double bv = s - p1;
     const double es = (p1 - (s - bv)) + (p2 - bv);
     const double tail = es + (e1 + e2);
-    const double r = sqrt(s);
-    if (!(r > 0.0) || !isfinite(r))
-        return r;
+    if (!(s > 0.0) || !isfinite(s))
+        return s;                            // 0, inf or NaN
+    const double inv = rsqrt_nr(s);
+    const double r = s * inv;
     const double rr = r * r, er = fma(r, r, -rr);
     const double resid = ((s - rr) - er) + tail;
-    return r + resid / (2.0 * r);
+    return fma(resid, 0.5 * inv, r);
 }
 
 __device__ __forceinline__ double next_up(double v) { return __longlong_as_double(__double_as_longlong(v) + 1); }

@@ -65,7 +65,10 @@ __global__ __launch_bounds__(RES_BLOCK) void residuals_kernel(
         ledge[b] = edges[b];
     __syncthreads();
     const double e0 = H > 0 ? ledge[0] : 0.0, eH = H > 0 ? ledge[H] : 0.0;
-    const double span = eH - e0;
+    // numpy.histogram puts d into the bin b with edges[b] <= d < edges[b+1] (last bin closed): it
+    // guesses b by scaling and repairs the guess against the edges.  Any guess within one bin of the
+    // truth gives the same b, so the guess here multiplies by H / span instead of dividing.
+    const double scale = (double)H / (eH - e0);
     Extreme mx{0.0, -1}, mn{0.0, -1};
     for (int64_t i = threadIdx.x; i < n; i += RES_BLOCK) {
         const double dx = x[off + i] - cx, dy = y[off + i] - cy;
@@ -77,11 +80,10 @@ __global__ __launch_bounds__(RES_BLOCK) void residuals_kernel(
         if (mx.i < 0 ? (r == r) : (r > mx.r)) { mx.r = r; mx.i = i; }
         if (mn.i < 0 ? (r == r) : (r < mn.r)) { mn.r = r; mn.i = i; }
         if (H > 0 && d >= e0 && d <= eH) {
-            // numpy.histogram: scaled index, then the two edge corrections
-            int32_t b = (int32_t)(((d - e0) / span) * (double)H);
-            if (b == H) b--;
+            int32_t b = (int32_t)((d - e0) * scale);
+            b = b > H - 1 ? H - 1 : b;
             if (d < ledge[b]) b--;
-            else if (d >= ledge[b + 1] && b != H - 1) b++;
+            else if (b < H - 1 && d >= ledge[b + 1]) b++;
             atomicAdd(&lhist[b], 1);
         }
     }

@@ -426,3 +426,85 @@ def test_full_size_ransac_30pct_outliers():
         o = N.ransac(np.stack([x[sl], y[sl]], 1), 0.5, 1024, 0.1)
         assert (o["score"], o["best_trial"]) == (r["score"][s], r["best_trial"][s])
         assert np.array_equal(o["mask"], r["mask"][sl]) and np.array_equal(o["model"], r["model"][s])
+
+
+# ------------------------------------------------------------------ long slices, scan-sized inputs
+def test_unique_hull_on_slices_longer_than_lds():
+    """Slices of 20 000 and 70 000 points take the global-memory variant of the sort / hull kernel."""
+    gen = np.random.default_rng(11)
+    sets = []
+    for n, outl in ((20_000, 0.0), (70_000, 0.2), (3_000, 0.0)):
+        th = gen.uniform(0, 2 * np.pi, n)
+        rr = 10.0 + gen.normal(0, 0.05, n)
+        bad = gen.random(n) < outl
+        rr[bad] = gen.uniform(0, 14.0, int(bad.sum()))
+        xy = np.stack([3 + rr * np.cos(th), -2 + rr * np.sin(th)], 1)
+        xy[::50] = xy[1::50][: len(xy[::50])]                 # duplicates
+        sets.append(xy)
+    x, y, off = csr(sets)
+    h = F.unique_hull_batch(x, y, off)
+    for s, xy in enumerate(sets):
+        uniq = R.unique_rows(xy)
+        o = off[s]
+        nu, nh = int(h["n_unique"][s]), int(h["n_hull"][s])
+        assert nu == len(uniq)
+        assert np.array_equal(h["ux"][o:o + nu], uniq[:, 0]) and np.array_equal(h["uy"][o:o + nu], uniq[:, 1])
+        assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
+    hy = F.hybrid_batch(x, y, off, max_trials=300)
+    assert np.all(hy["status"] == 0)
+    for s, xy in enumerate(sets):
+        ref = R.hybrid_fit(np.column_stack([xy, np.zeros(len(xy))]), 0.0, 1.0, max_trials=300)
+        assert rel(hy["fit"][s], [ref["center_x"], ref["center_y"], ref["radius"]]) < 1e-9
+        c0, c1 = hy["cand_offsets"][s], hy["cand_offsets"][s + 1]
+        assert np.array_equal(np.stack([hy["cand_x"][c0:c1], hy["cand_y"][c0:c1]], 1), ref["candidates_xy"])
+        assert np.array_equal(hy["mask"][c0:c1], ref["inlier_mask"])
+
+
+def test_one_million_point_scan_through_the_analyzer():
+    """The reference's own CPU-runnable case: 1 M points, 200 windows; five windows replayed on the CPU."""
+    from pointcloud_amd import Config, CylinderAnalyzer
+    pts = R.make_cylinder(1_000_000, 200, seed=0)
+    az = CylinderAnalyzer(Config())
+    res = az.analyze_with_progress(pts)
+    assert len(res) == 200
+    zc = az.calculate_z_centers(pts)
+    assert np.array_equal([r["z_center"] for r in res], zc)
+    for s in (0, 57, 123, 198, 199):
+        want, _, warn = R.process_slice(pts, zc[s])
+        assert warn is None
+        got = res[s]
+        assert got["n_points_slice"] == want["n_points_slice"] and got["n_edge"] == want["n_edge"]
+        assert got["boundary_points"] == want["boundary_points"]
+        for key in ("cx", "cy", "R", "Rmax", "Rmin", "ovality_abs", "ovality_pct"):
+            assert abs(got[key] - want[key]) <= 1e-9 * max(1.0, abs(want[key])), (s, key)
+        for key in ("x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin"):
+            assert got[key] == want[key]
+        assert abs(got["k2_amp"] - want["k2_amp"]) < 1e-12
+
+
+def test_scan_sized_boundary_and_histogram_pass():
+    """20 M points in 400 windows (50 000 per window): binning, Kasa + LM from global memory, angular-bin
+    boundary and residual histograms; eight windows replayed on the CPU."""
+    n, S = 20_000_000, 400
+    pts = R.make_cylinder(n, S, seed=3, outlier_frac=0.1)
+    zc, lo, hi = R.slice_windows(0.0, S * 2.0, 2.0)
+    off, x, y, _ = F.bin_slices(pts, lo, hi, want_perm=False)
+    z = pts[:, 2]
+    kasa, st = F.kasa_batch(x, y, off)
+    fit, iters = F.lm_batch(x, y, off, kasa)
+    sel = F.angle_max_batch(x, y, off, fit, bins=720)
+    res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
+    assert off[-1] == np.count_nonzero((z >= lo[0]) & (z <= hi[-1])) + np.count_nonzero(np.isin(z, lo[1:]))
+    for s in np.random.default_rng(2).choice(S, 8, replace=False):
+        m = R.slice_members(z, lo[s], hi[s])
+        assert off[s + 1] - off[s] == m.size
+        assert np.array_equal(x[off[s]:off[s + 1]], pts[m, 0]) and np.array_equal(y[off[s]:off[s + 1]], pts[m, 1])
+        xy = pts[m, :2]
+        so, ko = N.kasa(xy[:, 0], xy[:, 1])
+        assert rel(kasa[s], ko) < 1e-11
+        lo_, _, _ = N.lm(xy[:, 0], xy[:, 1], ko)
+        assert rel(fit[s], lo_) < LM_TOL[1]                     # 10 % outliers: noise-limited stopping rule
+        assert np.array_equal(N.angle_max(xy, fit[s][0], fit[s][1], 720), sel[s])
+        o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
+        assert np.array_equal(o["hist"], res["hist"][s])
+        assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
