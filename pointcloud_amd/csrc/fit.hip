@@ -2,14 +2,20 @@
 //   kasa_kernel  - algebraic fit   (fit_circle_pratt,      circle_fitting.py:35-54)
 //   lm_kernel    - geometric refit (lm_circle_geometric,   circle_fitting.py:57-109)
 //   fit_kernel   - both in one launch, the slice read from HBM once
+//   fit_residual_kernel - both plus the residual statistics, still one read
 //
-// Layout: a slice of up to 256*PT points lives in the registers of a 256-thread
-// workgroup (thread t holds points t, t+256, ...: coalesced 8-byte loads), so
-// every pass of the iteration runs out of the register file; longer slices are
-// re-read from global memory (L2 / Infinity Cache) pass after pass.  Sums use a
-// fixed butterfly + wave order, so results are bitwise reproducible.  Nothing
-// here is a dense contraction: the bound is the FP64 vector rate (sqrt and
-// divide per point and pass), not MFMA and not HBM.
+// A slice stays on chip for all passes of the iteration.  Thread t of a
+// workgroup of FIT_BLOCK threads owns points t, t+FIT_BLOCK, ... (coalesced
+// loads): the first PT_R of them live in its registers, the next PT_L in LDS.
+// Slices of up to 4096 points are all registers (16 points = 64 VGPRs per
+// thread); up to 8192 points half of the slice goes to LDS (64 KB), which
+// leaves the register file and the LDS of a CU room for two workgroups: while
+// one sits in a reduction or solves its 3x3 system the other one's sweep keeps
+// the vector units busy.  Longer slices are re-read from global memory (L2 /
+// Infinity Cache) pass after pass.  Sums use a fixed butterfly + wave order, so
+// results are bitwise reproducible.  Nothing here is a dense contraction: the
+// bound is the FP64 vector rate (a reciprocal square root and some forty
+// multiply-adds per point and pass), not MFMA and not HBM.
 #include <stdlib.h>
 #include <string.h>
 
@@ -19,82 +25,251 @@
 
 namespace pcfit {
 
+// dynamic LDS of the kernels in this file
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 
-// A slice as seen by one thread.  PT > 0: register resident (n <= 256*PT).
-// PT == 0: streamed from global memory on every pass.
-template <int PT, int FIT_BLOCK>
+// Optional phase timing (tools only; -DPCFIT_PHASE_CLOCK): thread 0 of every
+// workgroup adds the clocks spent between marks to g_phase[k].
+#ifdef PCFIT_PHASE_CLOCK
+__device__ unsigned long long g_phase[16];
+struct Phase {
+    long long last;
+    __device__ __forceinline__ void init() { last = clock64(); }
+    __device__ __forceinline__ void mark(int k)
+    {
+        if (threadIdx.x == 0) {
+            const long long now = clock64();
+            atomicAdd(&g_phase[k], (unsigned long long)(now - last));
+            last = now;
+        }
+    }
+};
+#else
+struct Phase {
+    __device__ __forceinline__ void init() {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
+
+// How a workgroup walks over the points of its slice.  Thread t visits points
+// t, t+STRIDE, t+2*STRIDE, ... in that order, GROUP of them at a time:
+//     full_groups(fg):  fg(px[GROUP], py[GROUP], i0)   points i0 + u*STRIDE, u < GROUP,
+//                       for every group in which all threads hold GROUP points of the slice;
+//     ragged_group(fg): the same call, at most once, for the group at the end of the slice in
+//                       which only the points with an index below n count (the coordinates of
+//                       the others are zeros or a repeat of the last point).
+// The bulk of a slice thus runs through bodies without any per-point branch, so
+// that the dependency chains of the GROUP points interleave.
+//
+// Storage: points [0, PT_R*FIT_BLOCK) in registers, the next PT_L*FIT_BLOCK as
+// (x, y) pairs in LDS at lds_dyn[0 ..); with PT_R == PT_L == 0 the slice is
+// streamed from global memory on every pass.  A slice longer than the storage
+// is cut there (callers pick the storage from the longest slice of the batch).
+template <int PT_R, int PT_L, int FIT_BLOCK>
 struct SliceView {
+    static constexpr bool STREAM = PT_R == 0 && PT_L == 0;
+    // (with 64 VGPRs of points per thread a group of 4 no longer fits the register file beside them)
+    static constexpr int GROUP = PT_R >= 16 ? 2 : ((STREAM || (PT_R % 4 == 0 && PT_L % 4 == 0)) ? 4 : 1);
+    static constexpr int STRIDE = FIT_BLOCK;
+    static constexpr int LDS_DOUBLES = 2 * PT_L * FIT_BLOCK;       // what the points take of lds_dyn
     const double *xs, *ys;
     int64_t n;
-    double rx[PT > 0 ? PT : 1], ry[PT > 0 ? PT : 1];
+    double rx[PT_R > 0 ? PT_R : 1], ry[PT_R > 0 ? PT_R : 1];
 
     __device__ __forceinline__ void load(const double *x, const double *y, int64_t off, int64_t count)
     {
         xs = x + off;
         ys = y + off;
         n = count;
-        if constexpr (PT > 0) {
+        if constexpr (!STREAM) {
+            if (n > (int64_t)(PT_R + PT_L) * FIT_BLOCK)
+                n = (int64_t)(PT_R + PT_L) * FIT_BLOCK;
+        }
+        // every load is unconditional (a point past the end reads the slice's last one and is then
+        // replaced by zero), so that all of them can be in flight together
+        const int64_t last = n > 0 ? n - 1 : 0;
+        if (n > 0) {
 #pragma unroll
-            for (int k = 0; k < PT; k++) {
+            for (int k = 0; k < PT_R; k++) {
                 const int64_t i = threadIdx.x + k * FIT_BLOCK;
-                rx[k] = i < n ? xs[i] : 0.0;
-                ry[k] = i < n ? ys[i] : 0.0;
+                const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
+                rx[k] = i < n ? vx : 0.0;
+                ry[k] = i < n ? vy : 0.0;
+            }
+            // the LDS part travels through registers
+#pragma unroll
+            for (int k = 0; k < PT_L; k++) {
+                const int64_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
+                const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
+                const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
+                lds_dyn[2 * j] = vx;
+                lds_dyn[2 * j + 1] = vy;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PT_R; k++)
+                rx[k] = ry[k] = 0.0;
+        }
+        if constexpr (PT_L > 0)
+            __syncthreads();
+    }
+
+    template <class FG>
+    __device__ __forceinline__ void full_groups(FG &&fg) const
+    {
+        constexpr int U = GROUP;
+        if constexpr (STREAM) {
+            for (int64_t first = 0; first + U * FIT_BLOCK <= n; first += U * FIT_BLOCK) {
+                double px[U], py[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    px[u] = xs[first + u * FIT_BLOCK + threadIdx.x];
+                    py[u] = ys[first + u * FIT_BLOCK + threadIdx.x];
+                }
+                fg(px, py, (int32_t)(first + threadIdx.x));
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < PT_R / U; g++) {
+                if ((g + 1) * U * FIT_BLOCK <= n) {
+                    double px[U], py[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        px[u] = rx[g * U + u];
+                        py[u] = ry[g * U + u];
+                    }
+                    fg(px, py, g * U * FIT_BLOCK + (int32_t)threadIdx.x);
+                }
+            }
+            if constexpr (PT_L > 0) {
+                // a rolled loop with a uniform trip count; the pairs of the next trip are read before
+                // the current ones are worked on
+                const int32_t in_lds = (int32_t)n - PT_R * FIT_BLOCK;
+                const int32_t trips = in_lds > 0 ? in_lds / (U * FIT_BLOCK) : 0;
+                double qx[U], qy[U];
+                int32_t j = threadIdx.x;
+                if (trips > 0) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        qx[u] = lds_dyn[2 * (j + u * FIT_BLOCK)];
+                        qy[u] = lds_dyn[2 * (j + u * FIT_BLOCK) + 1];
+                    }
+                }
+                for (int32_t t = 0; t < trips; t++, j += U * FIT_BLOCK) {
+                    double px[U], py[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        px[u] = qx[u];
+                        py[u] = qy[u];
+                    }
+                    const int32_t nxt = t + 1 < trips ? j + U * FIT_BLOCK : j;      // the last trip reads itself again
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        qx[u] = lds_dyn[2 * (nxt + u * FIT_BLOCK)];
+                        qy[u] = lds_dyn[2 * (nxt + u * FIT_BLOCK) + 1];
+                    }
+                    fg(px, py, PT_R * FIT_BLOCK + j);
+                }
             }
         }
     }
 
-    // f(x, y, slice-local index)
-    template <class F>
-    __device__ __forceinline__ void each_indexed(F &&f) const
+    template <class FG>
+    __device__ __forceinline__ void ragged_group(FG &&fg) const
     {
-        if constexpr (PT > 0) {
+        constexpr int U = GROUP;
+        const int64_t first = n / (U * FIT_BLOCK) * (U * FIT_BLOCK);
+        if (first == n)
+            return;
+        double px[U], py[U];
+        if constexpr (STREAM) {
 #pragma unroll
-            for (int k = 0; k < PT; k++) {
-                const int32_t i = (int32_t)threadIdx.x + k * FIT_BLOCK;
-                if (i < n)
-                    f(rx[k], ry[k], i);
-                if ((k & 3) == 3)
-                    __builtin_amdgcn_sched_barrier(0);      // keep the unrolled bodies from piling up in registers
+            for (int u = 0; u < U; u++) {
+                const int64_t i = first + u * FIT_BLOCK + threadIdx.x;
+                px[u] = xs[i < n - 1 ? i : n - 1];
+                py[u] = ys[i < n - 1 ? i : n - 1];
             }
         } else {
-            for (int64_t i = threadIdx.x; i < n; i += FIT_BLOCK)
-                f(xs[i], ys[i], (int32_t)i);
-        }
-    }
-
-    template <class F>
-    __device__ __forceinline__ void each(F &&f) const
-    {
-        if constexpr (PT > 0) {
 #pragma unroll
-            for (int k = 0; k < PT; k++)
-                if ((int64_t)(threadIdx.x + k * FIT_BLOCK) < n)
-                    f(rx[k], ry[k]);
-        } else {
-            for (int64_t i = threadIdx.x; i < n; i += FIT_BLOCK)
-                f(xs[i], ys[i]);
+            for (int u = 0; u < U; u++)
+                px[u] = py[u] = 0.0;
+#pragma unroll
+            for (int g = 0; g < PT_R / U; g++) {
+                if (first == g * U * FIT_BLOCK) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        px[u] = rx[g * U + u];
+                        py[u] = ry[g * U + u];
+                    }
+                }
+            }
+            if constexpr (PT_L > 0) {
+                if (first >= PT_R * FIT_BLOCK) {
+                    const int32_t j = (int32_t)first - PT_R * FIT_BLOCK + (int32_t)threadIdx.x;
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        px[u] = lds_dyn[2 * (j + u * FIT_BLOCK)];
+                        py[u] = lds_dyn[2 * (j + u * FIT_BLOCK) + 1];
+                    }
+                }
+            }
         }
+        fg(px, py, (int32_t)first + (int32_t)threadIdx.x);
     }
 };
 
+// f(x, y, i, valid) for every point of the slice and, in the ragged group, the slots past its end
+template <class View, class F>
+__device__ __forceinline__ void each_point(const View &P, F &&f)
+{
+    P.full_groups([&](const double (&px)[View::GROUP], const double (&py)[View::GROUP], int32_t i0) {
+#pragma unroll
+        for (int u = 0; u < View::GROUP; u++)
+            f(px[u], py[u], i0 + u * View::STRIDE, true);
+    });
+    P.ragged_group([&](const double (&px)[View::GROUP], const double (&py)[View::GROUP], int32_t i0) {
+#pragma unroll
+        for (int u = 0; u < View::GROUP; u++) {
+            const int32_t i = i0 + u * View::STRIDE;
+            f(px[u], py[u], i, i < P.n);
+        }
+    });
+}
+
+// Static LDS of a fit kernel, in doubles: two scratch areas for the workgroup
+// reductions (13 values x 16 waves each, used alternately) and two areas for
+// totals (12 sums and a minimum).
+constexpr int RED_SCR = 13 * 16, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 32;
+
+// Where the next reduction of a workgroup puts its partial sums.  Alternating
+// between two scratch areas (and never writing totals that may still be read)
+// lets a reduction do without a barrier on entry.
+struct RedCtx {
+    double *lds;
+    int count;
+    __device__ __forceinline__ double *scratch() { return lds + (count++ & 1) * RED_SCR; }
+    __device__ __forceinline__ double *totals(int which) { return lds + RED_TOT + 16 * which; }
+};
+
 // circle_fitting.py:35-54.  Uniform result in every thread.
-template <int PT, int FIT_BLOCK>
-__device__ __forceinline__ int kasa_slice(const SliceView<PT, FIT_BLOCK> &P, double *lds, double out[3])
+template <int NW, class View>
+__device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out[3])
 {
     out[0] = out[1] = out[2] = __longlong_as_double(0x7ff8000000000000ll);
     if (P.n < 3)
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
     double s1[2] = {0.0, 0.0};
-    P.each([&](double px, double py) {
-        s1[0] += px;
-        s1[1] += py;
+    each_point(P, [&](double px, double py, int32_t, bool valid) {
+        s1[0] += valid ? px : 0.0;
+        s1[1] += valid ? py : 0.0;
     });
-    block_sum<2>(s1, lds);
-    const double mx = s1[0] / n, my = s1[1] / n;
+    double *tot = red.totals(0);
+    block_reduce_to_lds<2, false, NW>(s1, 0.0, red.scratch(), tot);
+    const double mx = tot[0] / n, my = tot[1] / n;
     double m[7] = {0, 0, 0, 0, 0, 0, 0};   // suu svv suv suuu svvv suvv svuu
-    P.each([&](double px, double py) {
-        const double u = px - mx, v = py - my;
+    each_point(P, [&](double px, double py, int32_t, bool valid) {
+        const double u = valid ? px - mx : 0.0, v = valid ? py - my : 0.0;
         const double uu = u * u, vv = v * v;
         m[0] += uu;
         m[1] += vv;
@@ -104,7 +279,11 @@ __device__ __forceinline__ int kasa_slice(const SliceView<PT, FIT_BLOCK> &P, dou
         m[5] = fma(u, vv, m[5]);
         m[6] = fma(v, uu, m[6]);
     });
-    block_sum<7>(m, lds);
+    tot = red.totals(1);
+    block_reduce_to_lds<7, false, NW>(m, 0.0, red.scratch(), tot);
+#pragma unroll
+    for (int k = 0; k < 7; k++)
+        m[k] = tot[k];
     const double a = 2 * m[0], b = 2 * m[2], d = 2 * m[1];
     const double r0 = m[3] + m[5], r1 = m[4] + m[6];
     double uc, vc;
@@ -136,47 +315,66 @@ __device__ __forceinline__ int kasa_slice(const SliceView<PT, FIT_BLOCK> &P, dou
     return st;
 }
 
-// 3x3 Gaussian elimination with partial pivoting; false on an exactly zero pivot
+// 3x3 Gaussian elimination with partial pivoting (first largest entry of the
+// column, as LAPACK's pivot search); false on an exactly zero pivot.  Row swaps
+// are selects and each pivot is inverted once (Newton-refined reciprocal), as
+// LAPACK scales a pivot column, so the whole solve is a short branch-free chain:
+// every thread of the workgroup runs it between two sweeps.
+__device__ __forceinline__ double rcp_nr(double a)
+{
+    double y = __builtin_amdgcn_rcp(a);
+    double e = fma(-a, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-a, y, 1.0);
+    return fma(y, e, y);
+}
+
+__device__ __forceinline__ void swap_if(bool c, double &a, double &b)
+{
+    const double t = c ? b : a;
+    b = c ? a : b;
+    a = t;
+}
+
 __device__ __forceinline__ bool solve3x3(double A[3][3], double b[3], double x[3])
 {
+    // column 0
+    const bool p1 = fabs(A[1][0]) > fabs(A[0][0]);
+    const bool p2 = fabs(A[2][0]) > fmax(fabs(A[0][0]), fabs(A[1][0]));
+    const bool s1 = p1 && !p2;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        int p = k;
-#pragma unroll
-        for (int i = k + 1; i < 3; i++)
-            if (fabs(A[i][k]) > fabs(A[p][k]))
-                p = i;
-        if (p != k) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const double t = A[k][j];
-                A[k][j] = A[p][j];
-                A[p][j] = t;
-            }
-            const double t = b[k];
-            b[k] = b[p];
-            b[p] = t;
-        }
-        const double piv = A[k][k];
-        if (piv == 0.0)
-            return false;
-#pragma unroll
-        for (int i = k + 1; i < 3; i++) {
-            const double l = A[i][k] / piv;
-#pragma unroll
-            for (int j = k + 1; j < 3; j++)
-                A[i][j] -= l * A[k][j];
-            b[i] -= l * b[k];
-        }
+    for (int j = 0; j < 3; j++) {
+        swap_if(s1, A[0][j], A[1][j]);
+        swap_if(p2, A[0][j], A[2][j]);
     }
-#pragma unroll
-    for (int k = 2; k >= 0; k--) {
-        double s = b[k];
-#pragma unroll
-        for (int j = k + 1; j < 3; j++)
-            s -= A[k][j] * x[j];
-        x[k] = s / A[k][k];
-    }
+    swap_if(s1, b[0], b[1]);
+    swap_if(p2, b[0], b[2]);
+    if (A[0][0] == 0.0)
+        return false;
+    const double i0 = rcp_nr(A[0][0]);
+    const double l1 = A[1][0] * i0, l2 = A[2][0] * i0;
+    A[1][1] -= l1 * A[0][1];
+    A[1][2] -= l1 * A[0][2];
+    b[1] -= l1 * b[0];
+    A[2][1] -= l2 * A[0][1];
+    A[2][2] -= l2 * A[0][2];
+    b[2] -= l2 * b[0];
+    // column 1
+    const bool q = fabs(A[2][1]) > fabs(A[1][1]);
+    swap_if(q, A[1][1], A[2][1]);
+    swap_if(q, A[1][2], A[2][2]);
+    swap_if(q, b[1], b[2]);
+    if (A[1][1] == 0.0)
+        return false;
+    const double i1 = rcp_nr(A[1][1]);
+    const double l = A[2][1] * i1;
+    A[2][2] -= l * A[1][2];
+    b[2] -= l * b[1];
+    if (A[2][2] == 0.0)
+        return false;
+    x[2] = b[2] * rcp_nr(A[2][2]);
+    x[1] = (b[1] - A[1][2] * x[2]) * i1;
+    x[0] = (b[0] - A[0][1] * x[1] - A[0][2] * x[2]) * i0;
     return true;
 }
 
@@ -184,24 +382,6 @@ struct LmParams {
     double delta, lam0, tol_update, tol_cost;
     int32_t max_iter;
 };
-
-// smallest value over the workgroup (order independent)
-__device__ __forceinline__ double block_min(double v, double *scratch)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fmin(v, __shfl_xor(v, m, WAVE));
-    const int nw = blockDim.x >> 6;
-    if (nw == 1)
-        return v;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0)
-        scratch[threadIdx.x >> 6] = v;
-    __syncthreads();
-    for (int w = 0; w < nw; w++)
-        v = fmin(v, scratch[w]);
-    return v;
-}
 
 // circle_fitting.py:80-109.  Every accept / reject decision is the reference's
 // (cost of the candidate against the last accepted cost).  Two things the
@@ -221,8 +401,9 @@ __device__ __forceinline__ double block_min(double v, double *scratch)
 //    follow: the remaining iterations are all rejections.  The same holds
 //    when a rejected candidate equals the current parameters bit for bit.
 //    The iteration count the literal loop would have reached is reported.
-template <int PT, int FIT_BLOCK>
-__device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, const LmParams prm, double *lds, double par[3], int32_t iters[4])
+template <int NW, class View>
+__device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedCtx &red, double par[3],
+                                         int32_t iters[4], Phase &ph)
 {
     double cx = par[0], cy = par[1], rad = par[2];
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -233,61 +414,127 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
     // Huber-weighted problem, the curvature sum and the Huber cost, all from the same distances.
     //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
     //   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones
-    // The totals of a sweep stay in LDS (tot, 12 doubles): they are the same for every thread, and
-    // keeping two sets of them in registers would cost 48 VGPRs per lane.
-    auto sweep = [&](double px0, double py0, double pr, double *tot, double &lo_ri) {
+    // The totals of a sweep stay in LDS (tot: 12 sums, then the smallest distance): they are the
+    // same for every thread, and keeping two sets of them in registers would cost 48 VGPRs per lane.
+    //
+    // Two forms of the pass.  The short one takes every point for a regular one: at a distance
+    // above zero, within the Huber threshold, inside the slice; no branch, no select, and it notes
+    // whether any point was not regular.  The general one handles all points with selects.  For a
+    // regular point both give the same bits.  A sweep runs the short form over the full groups (and
+    // the general one over the ragged group); when a point turns out not to be regular the sweep
+    // is run again in the general form, and so are all later sweeps of this slice.
+    bool general = false;
+    auto sweep = [&](double px0, double py0, double pr, double *tot) {
+        constexpr int U = View::GROUP;
         double acc[12];
+        double low;
+        auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const bool valid = !check || i0 + u * View::STRIDE < P.n;
+                const double dx = px[u] - px0, dy = py[u] - py0;
+                const double d2 = fma(dx, dx, dy * dy);
+                const bool pos = d2 > 0.0;
+                // ri = sqrt(d2) + 1e-16 and 1/ri (first order in the 1e-16)
+                const double y0 = rsqrt_nr(d2);
+                const double y = pos ? y0 : 0.0;
+                const double ri = fma(d2, y, 1e-16);
+                const double iv = pos ? fma(-1e-16 * y0, y0, y0) : 1e16;
+                const double res = ri - pr;
+                const double a = fabs(res);
+                const bool big = a > delta;
+                const double sw = root_delta * rsqrt_nr(a + 1e-16);      // sqrt(delta / (a + 1e-16))
+                double j0 = -dx * iv, j1 = -dy * iv;
+                j0 = big ? j0 * sw : j0;
+                j1 = big ? j1 * sw : j1;
+                double j2 = big ? -sw : -1.0;
+                double rw = big ? res * sw : res;
+                double psi = big ? delta : a;
+                j0 = valid ? j0 : 0.0;
+                j1 = valid ? j1 : 0.0;
+                j2 = valid ? j2 : 0.0;
+                rw = valid ? rw : 0.0;
+                psi = valid ? psi : 0.0;
+                const double c11 = fma(delta, a - 0.5 * delta, acc[11]), c10 = fma(a, a, acc[10]);
+                acc[11] = (valid && big) ? c11 : acc[11];
+                acc[10] = (valid && !big) ? c10 : acc[10];
+                acc[0] = fma(j0, j0, acc[0]);
+                acc[1] = fma(j0, j1, acc[1]);
+                acc[2] = fma(j0, j2, acc[2]);
+                acc[3] = fma(j1, j1, acc[3]);
+                acc[4] = fma(j1, j2, acc[4]);
+                acc[5] = fma(j2, j2, acc[5]);
+                acc[6] = fma(j0, rw, acc[6]);
+                acc[7] = fma(j1, rw, acc[7]);
+                acc[8] = fma(j2, rw, acc[8]);
+                acc[9] = fma(psi, iv, acc[9]);
+                low = valid ? fmin(low, ri) : low;
+            }
+        };
+        auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, true); };
+        if (!general) {
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                acc[k] = 0.0;
+            low = inf;
+            bool odd = false;
+            P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const double dx = px[u] - px0, dy = py[u] - py0;
+                    const double d2 = fma(dx, dx, dy * dy);
+                    const double y0 = rsqrt_nr(d2);
+                    const double ri = fma(d2, y0, 1e-16);
+                    const double iv = fma(-1e-16 * y0, y0, y0);
+                    const double r = ri - pr;
+                    odd |= !(fabs(r) <= delta);          // also true for the NaN a zero distance gives here
+                    const double j0 = -dx * iv, j1 = -dy * iv;
+                    acc[10] = fma(r, r, acc[10]);
+                    acc[0] = fma(j0, j0, acc[0]);
+                    acc[1] = fma(j0, j1, acc[1]);
+                    acc[2] = acc[2] - j0;
+                    acc[3] = fma(j1, j1, acc[3]);
+                    acc[4] = acc[4] - j1;
+                    acc[5] = acc[5] + 1.0;
+                    acc[6] = fma(j0, r, acc[6]);
+                    acc[7] = fma(j1, r, acc[7]);
+                    acc[8] = acc[8] - r;
+                    acc[9] = fma(fabs(r), iv, acc[9]);
+                    low = min_no_nan(low, ri);
+                }
+            });
+            P.ragged_group(ragged);
+            low = odd ? -inf : low;             // the smallest distance doubles as the flag
+            ph.mark(2);
+            block_reduce_to_lds<12, true, NW>(acc, low, red.scratch(), tot);
+            ph.mark(3);
+            if (tot[12] != -inf)
+                return;
+            general = true;             // (every thread has read tot[12] before the barrier inside the next reduction)
+        }
 #pragma unroll
         for (int k = 0; k < 12; k++)
             acc[k] = 0.0;
-        double low = inf;
-        P.each([&](double px, double py) {
-            const double dx = px - px0, dy = py - py0;
-            const double d2 = fma(dx, dx, dy * dy);
-            // ri = sqrt(d2) + 1e-16 and 1/ri (first order in the 1e-16)
-            const double y0 = d2 > 0.0 ? rsqrt_nr(d2) : 0.0;
-            const double ri = fma(d2, y0, 1e-16);
-            const double inv = d2 > 0.0 ? fma(-1e-16 * y0, y0, y0) : 1e16;
-            const double r = ri - pr;
-            const double a = fabs(r);
-            double j0 = -dx * inv, j1 = -dy * inv, j2 = -1.0, rw = r;
-            double psi = a;
-            if (a > delta) {
-                const double sw = root_delta * rsqrt_nr(a + 1e-16);      // sqrt(delta / (a + 1e-16))
-                j0 *= sw;
-                j1 *= sw;
-                j2 = -sw;
-                rw = r * sw;
-                psi = delta;
-                acc[11] = fma(delta, a - 0.5 * delta, acc[11]);
-            } else {
-                acc[10] = fma(a, a, acc[10]);
-            }
-            acc[0] = fma(j0, j0, acc[0]);
-            acc[1] = fma(j0, j1, acc[1]);
-            acc[2] = fma(j0, j2, acc[2]);
-            acc[3] = fma(j1, j1, acc[3]);
-            acc[4] = fma(j1, j2, acc[4]);
-            acc[5] = fma(j2, j2, acc[5]);
-            acc[6] = fma(j0, rw, acc[6]);
-            acc[7] = fma(j1, rw, acc[7]);
-            acc[8] = fma(j2, rw, acc[8]);
-            acc[9] = fma(psi, inv, acc[9]);
-            low = fmin(low, ri);
-        });
-        block_sum_to_lds<12>(acc, lds, tot);
-        lo_ri = block_min(low, lds);
+        low = inf;
+        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false); });
+        P.ragged_group(ragged);
+        ph.mark(2);
+        block_reduce_to_lds<12, true, NW>(acc, low, red.scratch(), tot);
+        ph.mark(3);
     };
 
-    double *hg = lds + 12 * 16, *trial = lds + 12 * 16 + 12;      // LDS: current and candidate totals
-    double min_ri = 0.0, trial_min;
+    int cur = -1;                               // which totals area holds H, g at (cx, cy, rad); none yet
+    const double *hg = red.totals(0);
+    double min_ri = 0.0;
     double tx = cx, ty = cy, tr = rad;          // what the next sweep evaluates: first the start itself
     double step[3] = {0.0, 0.0, 0.0};
     bool first = true;
     int32_t it = 0, acc_steps = 0, n_first = 0, n_sweeps = 0;
-    // (one call site for the sweep: its unrolled body is the bulk of the kernel's code)
+    // (one call site for the sweep: its body is the bulk of the kernel's code)
     while (prm.max_iter > 0) {
-        sweep(tx, ty, tr, trial, trial_min);
+        const int into = cur == 0 ? 1 : 0;      // never the area the current H, g live in
+        const double *trial = red.totals(into);
+        sweep(tx, ty, tr, red.totals(into));
         bool adopt, done = false;
         if (first) {
             // H and g at the start; its cost is not used (the reference starts from cost_prev = inf)
@@ -318,11 +565,9 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
             }
         }
         if (adopt) {
-            __syncthreads();                     // everyone has read trial[10..11] and the old totals
-            if (threadIdx.x < 10)
-                hg[threadIdx.x] = trial[threadIdx.x];
-            __syncthreads();
-            min_ri = trial_min;
+            cur = into;
+            hg = trial;
+            min_ri = trial[12];
         }
         if (done)
             break;
@@ -368,20 +613,22 @@ __device__ __forceinline__ void lm_slice(const SliceView<PT, FIT_BLOCK> &P, cons
     iters[1] = acc_steps;   // accepted steps
     iters[2] = n_first;     // sweeps that only built H and g (the first)
     iters[3] = n_sweeps;    // sweeps that evaluated a candidate (cost, and H and g for the next step)
+    ph.mark(4);
 }
 
-template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT_R, int PT_L, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, 2) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                         const int64_t *__restrict__ offsets, double *__restrict__ out,
                                                         int32_t *__restrict__ status)
 {
-    __shared__ double lds[12 * 16 + 24];
+    __shared__ double lds[RED_SIZE];
+    RedCtx red{lds, 0};
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT, FIT_BLOCK> P;
+    SliceView<PT_R, PT_L, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3];
-    const int st = kasa_slice(P, lds, c);
+    const int st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -391,20 +638,23 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
     }
 }
 
-template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT_R, int PT_L, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, 2) void lm_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                       const int64_t *__restrict__ offsets,
                                                       const double *__restrict__ init, LmParams prm,
                                                       double *__restrict__ out, int32_t *__restrict__ iters)
 {
-    __shared__ double lds[12 * 16 + 24];
+    __shared__ double lds[RED_SIZE];
+    Phase ph;
+    ph.init();
+    RedCtx red{lds, 0};
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT, FIT_BLOCK> P;
+    SliceView<PT_R, PT_L, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3] = {init[3 * s], init[3 * s + 1], init[3 * s + 2]};
     int32_t it[4] = {0, 0, 0, 0};
-    lm_slice(P, prm, lds, c, it);
+    lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -419,19 +669,22 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
 
 // Kasa start, then LM, the slice read once.  status follows the Kasa fit; slices
 // whose Kasa fit is unavailable (n < 3) get NaN.
-template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
+template <int PT_R, int PT_L, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, 2) void fit_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                        const int64_t *__restrict__ offsets, LmParams prm,
                                                        double *__restrict__ kasa_out, double *__restrict__ out,
                                                        int32_t *__restrict__ iters, int32_t *__restrict__ status)
 {
-    __shared__ double lds[12 * 16 + 24];
+    __shared__ double lds[RED_SIZE];
+    Phase ph;
+    ph.init();
+    RedCtx red{lds, 0};
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT, FIT_BLOCK> P;
+    SliceView<PT_R, PT_L, FIT_BLOCK> P;
     P.load(x, y, off, n);
     double c[3];
-    const int st = kasa_slice(P, lds, c);
+    const int st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
     if (threadIdx.x == 0 && kasa_out) {
         kasa_out[3 * s] = c[0];
         kasa_out[3 * s + 1] = c[1];
@@ -439,7 +692,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
     }
     int32_t it[4] = {0, 0, 0, 0};
     if (st != PCFIT_ST_SPARSE)
-        lm_slice(P, prm, lds, c, it);
+        lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -471,61 +724,40 @@ __device__ __forceinline__ Extreme2 better_min(Extreme2 a, Extreme2 b)
     return (b.r < a.r || (b.r == a.r && b.i < a.i)) ? b : a;
 }
 
-// Kasa -> LM -> residual statistics with the slice read from HBM once:
-// histogram of dr = hypot - R (numpy.histogram rules, H bins, edges given),
-// Rmax / Rmin and the first index attaining each (analyzer.py:83-92,
-// gui.py:979-983).  Dynamic LDS: (H+1) doubles of edges, then H int32 counters.
-template <int PT, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 384 ? 3 : 2))) void fit_residual_kernel(
-    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
-    double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
-    int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
-    double *__restrict__ rmax_rmin, int64_t *__restrict__ argmax_argmin)
+// Residual statistics of one slice about the circle (cx, cy, R): histogram of
+// dr = hypot - R (numpy.histogram rules, H bins), Rmax / Rmin and the first
+// index attaining each (analyzer.py:83-92, gui.py:979-983).  The H+1 edges are
+// in LDS at lds_dyn[base ..], the H int32 counters (zeroed by the caller) follow.
+template <class View>
+__device__ __forceinline__ void residual_slice(const View &P, double cx, double cy, double R, int32_t H, int32_t base,
+                                               int64_t s, int64_t *__restrict__ hist, double *__restrict__ rmax_rmin,
+                                               int64_t *__restrict__ argmax_argmin, Extreme2 *wmax, Extreme2 *wmin)
 {
-    extern __shared__ double lds_dyn[];
-    __shared__ double lds[12 * 16 + 24];
-    __shared__ Extreme2 wmax[FIT_BLOCK / WAVE], wmin[FIT_BLOCK / WAVE];
-    double *ledge = lds_dyn;
-    int32_t *lhist = reinterpret_cast<int32_t *>(lds_dyn + (H > 0 ? H + 1 : 0));
-    const int64_t s = blockIdx.x;
-    const int64_t off = offsets[s], n = offsets[s + 1] - off;
-    SliceView<PT, FIT_BLOCK> P;
-    P.load(x, y, off, n);
-    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
-        lhist[b] = 0;
-    for (int b = threadIdx.x; b <= H && H > 0; b += FIT_BLOCK)
-        ledge[b] = edges[b];
-    double c[3];
-    const int st = kasa_slice(P, lds, c);
-    if (threadIdx.x == 0 && kasa_out) {
-        kasa_out[3 * s] = c[0];
-        kasa_out[3 * s + 1] = c[1];
-        kasa_out[3 * s + 2] = c[2];
-    }
-    int32_t it[4] = {0, 0, 0, 0};
-    if (st != PCFIT_ST_SPARSE)
-        lm_slice(P, prm, lds, c, it);
-    __syncthreads();
-    const double cx = c[0], cy = c[1], R = c[2];
-    const double e0 = H > 0 ? ledge[0] : 0.0, eH = H > 0 ? ledge[H] : 0.0;
+    const double e0 = H > 0 ? lds_dyn[base] : 0.0, eH = H > 0 ? lds_dyn[base + H] : 0.0;
     // numpy.histogram puts d into the bin b with edges[b] <= d < edges[b+1] (last bin closed): it
     // guesses b by scaling and repairs the guess against the edges.  Any guess within one bin of the
     // truth gives the same b, so the guess here multiplies by H / span instead of dividing.
     const double scale = (double)H / (eH - e0);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     Extreme2 mx{-inf, -1}, mn{inf, -1};
-    P.each_indexed([&](double px, double py, int32_t i) {
+    // (no branch in the body but the one around the counter update, so that the points of a group interleave)
+    each_point(P, [&](double px, double py, int32_t i, bool valid) {
         const double r = cr_hypot(px - cx, py - cy);
         const double d = r - R;
-        if (r > mx.r) { mx.r = r; mx.i = i; }          // strict: the first index of an extreme value stays
-        if (r < mn.r) { mn.r = r; mn.i = i; }
-        if (H > 0 && d >= e0 && d <= eH) {
+        const bool up = valid && r > mx.r, dn = valid && r < mn.r;      // strict: the first index of an extreme value stays
+        mx.r = up ? r : mx.r;
+        mx.i = up ? i : mx.i;
+        mn.r = dn ? r : mn.r;
+        mn.i = dn ? i : mn.i;
+        if (H > 0) {
             // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
+            const bool in = valid && d >= e0 && d <= eH;
             int32_t b = (int32_t)((d - e0) * scale);
-            b = b > H - 1 ? H - 1 : b;
-            if (d < lds_dyn[b]) b--;
-            else if (b < H - 1 && d >= lds_dyn[b + 1]) b++;
-            atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + H + 1) + b, 1);
+            b = b < 0 ? 0 : (b > H - 1 ? H - 1 : b);
+            const double below = lds_dyn[base + b], above = lds_dyn[base + b + 1];
+            b += d < below ? -1 : ((b < H - 1 && d >= above) ? 1 : 0);
+            if (in)
+                atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + base + H + 1) + b, 1);
         }
     });
 #pragma unroll
@@ -543,10 +775,11 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
         wmin[threadIdx.x >> 6] = mn;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
+    const int32_t *lhist = reinterpret_cast<const int32_t *>(lds_dyn + base + H + 1);
+    for (int b = threadIdx.x; b < H; b += blockDim.x)
         hist[s * H + b] = (int64_t)lhist[b];
     if (threadIdx.x == 0) {
-        for (int w = 1; w < FIT_BLOCK / WAVE; w++) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
             mx = better_max(mx, wmax[w]);
             mn = better_min(mn, wmin[w]);
         }
@@ -554,9 +787,48 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
         rmax_rmin[2 * s + 1] = mn.r;
         argmax_argmin[2 * s] = mx.i;
         argmax_argmin[2 * s + 1] = mn.i;
-        out[3 * s] = cx;
-        out[3 * s + 1] = cy;
-        out[3 * s + 2] = R;
+    }
+}
+
+// Kasa -> LM -> residual statistics with the slice read from HBM once.
+// Dynamic LDS: the view's points, then (H+1) doubles of edges, then H int32 counters.
+template <int PT_R, int PT_L, int FIT_BLOCK>
+__global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
+    double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
+    int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
+    double *__restrict__ rmax_rmin, int64_t *__restrict__ argmax_argmin)
+{
+    __shared__ double lds[RED_SIZE];
+    __shared__ Extreme2 wmax[16], wmin[16];
+    Phase ph;
+    ph.init();
+    RedCtx red{lds, 0};
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], n = offsets[s + 1] - off;
+    SliceView<PT_R, PT_L, FIT_BLOCK> P;
+    P.load(x, y, off, n);
+    constexpr int base = SliceView<PT_R, PT_L, FIT_BLOCK>::LDS_DOUBLES;
+    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
+        reinterpret_cast<int32_t *>(lds_dyn + base + H + 1)[b] = 0;
+    for (int b = threadIdx.x; b <= H && H > 0; b += FIT_BLOCK)
+        lds_dyn[base + b] = edges[b];
+    double c[3];
+    const int st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
+    if (threadIdx.x == 0 && kasa_out) {
+        kasa_out[3 * s] = c[0];
+        kasa_out[3 * s + 1] = c[1];
+        kasa_out[3 * s + 2] = c[2];
+    }
+    int32_t it[4] = {0, 0, 0, 0};
+    if (st != PCFIT_ST_SPARSE)
+        lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
+    __syncthreads();
+    residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin);
+    if (threadIdx.x == 0) {
+        out[3 * s] = c[0];
+        out[3 * s + 1] = c[1];
+        out[3 * s + 2] = c[2];
         if (iters) {
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -568,69 +840,68 @@ __global__ __launch_bounds__(FIT_BLOCK, (FIT_BLOCK >= 1024 ? 4 : (FIT_BLOCK == 3
 }
 
 // Launch shape for a batch whose longest slice has max_len points: threads per
-// workgroup x points per thread (4 VGPRs each).  0 points per thread = stream
-// the slice from global memory on every pass.
+// workgroup, points per thread in registers (4 VGPRs each) and in LDS (16 bytes
+// each).  All zero points = stream the slice from global memory on every pass.
 struct FitShape {
-    int block, pt;
+    int block, pr, pl;
 };
 
 static FitShape pick_shape(int64_t max_len)
 {
-    if (max_len <= 0) return {256, 0};
-    if (max_len <= 64) return {64, 1};
-    if (max_len <= 256) return {256, 1};
-    if (max_len <= 1024) return {256, 4};
-    if (max_len <= 2048) return {256, 8};
-    if (max_len <= 4096) return {512, 8};
-    if (max_len <= 8192) {
-        static const FitShape big = [] {
-            // measured on MI355X, 10 000 slices x 8192 points: 256x32 beats 512x16 and 1024x8 (fewer waves
-            // to reduce over, more independent points per lane); the variable is a tuning knob
-            const char *e = getenv("PCFIT_FIT_SHAPE");
-            if (e && !strcmp(e, "512x16")) return FitShape{512, 16};
-            if (e && !strcmp(e, "384x22")) return FitShape{384, 22};
-            if (e && !strcmp(e, "320x26")) return FitShape{320, 26};
-            if (e && !strcmp(e, "1024x8")) return FitShape{1024, 8};
-            return FitShape{256, 32};
-        }();
-        return big;
-    }
-    return {256, 0};
+    if (max_len <= 0) return {256, 0, 0};
+    if (max_len <= 64) return {64, 1, 0};
+    if (max_len <= 256) return {256, 1, 0};
+    if (max_len <= 1024) return {256, 4, 0};
+    if (max_len <= 2048) return {256, 8, 0};
+    if (max_len <= 4096) return {256, 16, 0};
+    if (max_len <= 8192) return {256, 16, 16};
+    return {256, 0, 0};
 }
 
-template <int B, int P>
+template <int B, int PR, int PL>
 struct ShapeTag {
-    static constexpr int block = B, pt = P;
+    static constexpr int block = B, pr = PR, pl = PL;
+    static constexpr size_t lds_points = (size_t)PL * B * 16;
 };
 
-// calls f(ShapeTag<block, pt>)
+// calls f(ShapeTag<block, pr, pl>)
 template <class F>
 static void dispatch_shape(FitShape sh, F &&f)
 {
-    const int key = sh.block * 100 + sh.pt;
+    const int key = (sh.block * 100 + sh.pr) * 100 + sh.pl;
     switch (key) {
-    case 64 * 100 + 1: f(ShapeTag<64, 1>{}); break;
-    case 256 * 100 + 1: f(ShapeTag<256, 1>{}); break;
-    case 256 * 100 + 4: f(ShapeTag<256, 4>{}); break;
-    case 256 * 100 + 8: f(ShapeTag<256, 8>{}); break;
-    case 512 * 100 + 8: f(ShapeTag<512, 8>{}); break;
-    case 256 * 100 + 32: f(ShapeTag<256, 32>{}); break;
-    case 512 * 100 + 16: f(ShapeTag<512, 16>{}); break;
-    case 384 * 100 + 22: f(ShapeTag<384, 22>{}); break;
-    case 320 * 100 + 26: f(ShapeTag<320, 26>{}); break;
-    case 1024 * 100 + 8: f(ShapeTag<1024, 8>{}); break;
-    default: f(ShapeTag<256, 0>{}); break;
+    case (64 * 100 + 1) * 100: f(ShapeTag<64, 1, 0>{}); break;
+    case (256 * 100 + 1) * 100: f(ShapeTag<256, 1, 0>{}); break;
+    case (256 * 100 + 4) * 100: f(ShapeTag<256, 4, 0>{}); break;
+    case (256 * 100 + 8) * 100: f(ShapeTag<256, 8, 0>{}); break;
+    case (256 * 100 + 16) * 100: f(ShapeTag<256, 16, 0>{}); break;
+    case (256 * 100 + 16) * 100 + 16: f(ShapeTag<256, 16, 16>{}); break;
+    default: f(ShapeTag<256, 0, 0>{}); break;
     }
+}
+
+// dynamic LDS beyond 64 KB has to be asked for, per kernel
+template <class K>
+static int allow_lds(K kern, size_t bytes)
+{
+    if (bytes > 48 * 1024)
+        PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)bytes));
+    return PCFIT_OK;
 }
 
 int launch_kasa(const double *x, const double *y, const int64_t *offsets, int64_t S, int64_t max_len, double *out,
                 int32_t *status, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
+    int rc = PCFIT_OK;
     dispatch_shape(pick_shape(max_len), [&](auto t) {
         using T = decltype(t);
-        kasa_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, out, status);
+        auto kern = kasa_kernel<T::pr, T::pl, T::block>;
+        if ((rc = allow_lds(kern, T::lds_points)) != PCFIT_OK) return;
+        kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points, st>>>(x, y, offsets, out, status);
     });
+    PCFIT_TRY(rc);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -639,10 +910,14 @@ int launch_lm(const double *x, const double *y, const int64_t *offsets, int64_t 
               const double *init, const LmParams &prm, double *out, int32_t *iters, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
+    int rc = PCFIT_OK;
     dispatch_shape(pick_shape(max_len), [&](auto t) {
         using T = decltype(t);
-        lm_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, init, prm, out, iters);
+        auto kern = lm_kernel<T::pr, T::pl, T::block>;
+        if ((rc = allow_lds(kern, T::lds_points)) != PCFIT_OK) return;
+        kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points, st>>>(x, y, offsets, init, prm, out, iters);
     });
+    PCFIT_TRY(rc);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -651,11 +926,14 @@ int launch_fit(const double *x, const double *y, const int64_t *offsets, int64_t
                const LmParams &prm, double *kasa_out, double *out, int32_t *iters, int32_t *status, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
+    int rc = PCFIT_OK;
     dispatch_shape(pick_shape(max_len), [&](auto t) {
         using T = decltype(t);
-        fit_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), 0, st>>>(x, y, offsets, prm, kasa_out, out,
-                                                                                  iters, status);
+        auto kern = fit_kernel<T::pr, T::pl, T::block>;
+        if ((rc = allow_lds(kern, T::lds_points)) != PCFIT_OK) return;
+        kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points, st>>>(x, y, offsets, prm, kasa_out, out, iters, status);
     });
+    PCFIT_TRY(rc);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -665,12 +943,16 @@ int launch_fit_residual(const double *x, const double *y, const int64_t *offsets
                         const double *edges, int64_t *hist, double *rmm, int64_t *amm, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
-    const size_t lds = H > 0 ? (size_t)(H + 1) * 8 + (size_t)H * 4 : 0;
+    const size_t lds_hist = H > 0 ? (size_t)(H + 1) * 8 + (size_t)H * 4 : 0;
+    int rc = PCFIT_OK;
     dispatch_shape(pick_shape(max_len), [&](auto t) {
         using T = decltype(t);
-        fit_residual_kernel<T::pt, T::block><<<dim3((unsigned)S), dim3(T::block), lds, st>>>(
+        auto kern = fit_residual_kernel<T::pr, T::pl, T::block>;
+        if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
+        kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
             x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
     });
+    PCFIT_TRY(rc);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -728,3 +1010,17 @@ PCFIT_API int pcfit_fit_residuals_batch_dev(const double *x, const double *y, co
     return launch_fit_residual(x, y, offsets, n_slices, max_slice_len, prm, kasa_out, out, iters, status, n_bins,
                                edges, hist, rmax_rmin, argmax_argmin, as_stream(stream));
 }
+
+#ifdef PCFIT_PHASE_CLOCK
+// tools only: clocks accumulated per phase by thread 0 of every workgroup (16 counters)
+PCFIT_API int pcfit_debug_phase_clocks(int64_t *out16, int reset)
+{
+    PCFIT_HIP(hipDeviceSynchronize());
+    PCFIT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pcfit::g_phase), 16 * sizeof(int64_t)));
+    if (reset) {
+        int64_t zero[16] = {0};
+        PCFIT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pcfit::g_phase), zero, sizeof(zero)));
+    }
+    return PCFIT_OK;
+}
+#endif

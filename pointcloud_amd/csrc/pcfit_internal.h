@@ -156,6 +156,114 @@ __device__ __forceinline__ void block_sum_to_lds(double (&v)[K], double *scratch
     __syncthreads();
 }
 
+// Reduce-scatter butterfly over a wave: CNT values per lane go in; each exchange
+// halves the number of values a lane carries (a lane keeps one half and sends the
+// other to its partner), so summing K values over 64 lanes moves about K + 5
+// doubles per lane instead of 6 K.  Once one value is left the remaining
+// exchanges are plain butterflies.  At the end v[0] of lane l is the total of the
+// value with index rs_index<K, 32>(l) (lanes that differ only in the bits of
+// rs_lowmask<K, 32>() hold the same total).  The order of the additions is fixed.
+template <int CNT, int M, int K>
+__device__ __forceinline__ void rs_steps(double (&v)[K], int lane)
+{
+    if constexpr (M >= 1) {
+        if constexpr (CNT > 1) {
+            constexpr int H = (CNT + 1) / 2;
+            const bool up = (lane & M) != 0;
+#pragma unroll
+            for (int j = 0; j < H; j++) {
+                const double hi = (j + H < CNT) ? v[j + H] : 0.0;
+                const double send = up ? v[j] : hi;
+                const double keep = up ? hi : v[j];
+                v[j] = keep + __shfl_xor(send, M, WAVE);
+            }
+            rs_steps<H, M / 2>(v, lane);
+        } else {
+            v[0] += __shfl_xor(v[0], M, WAVE);
+            rs_steps<1, M / 2>(v, lane);
+        }
+    }
+}
+
+template <int CNT, int M>
+__device__ __forceinline__ int rs_index(int lane, bool &valid)
+{
+    if constexpr (M >= 1 && CNT > 1) {
+        constexpr int H = (CNT + 1) / 2;
+        const int loc = rs_index<H, M / 2>(lane, valid) + ((lane & M) ? H : 0);
+        if (loc >= CNT)
+            valid = false;              // a padding slot of an odd split
+        return loc;
+    } else {
+        return 0;
+    }
+}
+
+template <int CNT, int M>
+constexpr int rs_lowmask()
+{
+    if constexpr (M >= 1 && CNT > 1)
+        return rs_lowmask<(CNT + 1) / 2, M / 2>();
+    else
+        return M >= 1 ? 2 * M - 1 : 0;
+}
+
+// the smaller of two numbers, neither a NaN: one instruction (fmin() first quiets its operands)
+__device__ __forceinline__ double min_no_nan(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmin(v, __shfl_xor(v, m, WAVE));
+    return v;
+}
+
+// Sum K values per thread over a workgroup of NW waves and, when WITH_MIN, take
+// the smallest `low` as well; the K totals (and the minimum, at dst[K]) are left
+// in LDS for every thread to read after the call.  scratch: (K + 1) * 16 doubles.
+// Order: reduce-scatter butterfly inside a wave, then waves 0, 1, 2, ...
+// Two barriers; the caller alternates between two scratch areas (and makes sure
+// nobody still reads dst), so that none is needed on entry.
+template <int K, bool WITH_MIN, int NW>
+__device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, double *scratch, double *dst)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    rs_steps<K, 32>(v, lane);
+    bool valid = true;
+    const int k = rs_index<K, 32>(lane, valid);
+    if constexpr (WITH_MIN)
+        low = wave_min(low);
+    if (valid && (lane & rs_lowmask<K, 32>()) == 0)
+        scratch[k * 16 + wave] = v[0];
+    if (WITH_MIN && lane == 0)
+        scratch[K * 16 + wave] = low;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double part[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            part[w] = scratch[threadIdx.x * 16 + w];
+        double s = part[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+            s += part[w];
+        dst[threadIdx.x] = s;
+    } else if (WITH_MIN && threadIdx.x == K) {
+        double s = scratch[K * 16];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+            s = fmin(s, scratch[K * 16 + w]);
+        dst[K] = s;
+    }
+    __syncthreads();
+}
+
 // (theta, r) as the reference forms them: theta = (atan2(dy,dx) + 2pi) mod 2pi
 __device__ __forceinline__ double wrap_angle(double dy, double dx)
 {
@@ -186,13 +294,13 @@ __device__ __forceinline__ double cr_hypot(double x, double y)
     const double bv = s - p1;
     const double es = (p1 - (s - bv)) + (p2 - bv);
     const double tail = es + (e1 + e2);
-    if (!(s > 0.0) || !isfinite(s))
-        return s;                            // 0, inf or NaN
     const double inv = rsqrt_nr(s);
     const double r = s * inv;
     const double rr = r * r, er = fma(r, r, -rr);
     const double resid = ((s - rr) - er) + tail;
-    return fma(resid, 0.5 * inv, r);
+    const double h = fma(resid, 0.5 * inv, r);
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    return (s > 0.0 && s < inf) ? h : s;        // 0, inf or NaN pass through (a select, not a branch)
 }
 
 __device__ __forceinline__ double next_up(double v) { return __longlong_as_double(__double_as_longlong(v) + 1); }

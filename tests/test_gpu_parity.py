@@ -413,6 +413,77 @@ def test_fused_fit_residual_launch_equals_the_separate_kernels():
     assert st[-1] == 1 and np.all(np.isnan(of_.cpu().numpy()[-1]))
 
 
+def _fused_dev(x, y, off, H, lo, hi, want_resid=True):
+    """pcfit_fit_residuals_batch_dev (or pcfit_fit_batch_dev) on device copies of the inputs."""
+    import ctypes as C
+    import torch
+    S = len(off) - 1
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dx, dy, doff, dedge = t(x), t(y), t(off), t(np.linspace(lo, hi, H + 1))
+    ok_, of_ = torch.empty(S, 3, dtype=torch.float64, device=dev), torch.empty(S, 3, dtype=torch.float64, device=dev)
+    oi, os_ = torch.empty(S, 4, dtype=torch.int32, device=dev), torch.empty(S, dtype=torch.int32, device=dev)
+    oh = torch.zeros(S, H, dtype=torch.int64, device=dev)
+    orm, oam = torch.empty(S, 2, dtype=torch.float64, device=dev), torch.empty(S, 2, dtype=torch.int64, device=dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mx = int(np.diff(off).max())
+    if want_resid:
+        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, mx, 1.0, 100, 1e-2, 1e-10, 1e-12,
+                                                      p(ok_), p(of_), p(oi), p(os_), H, p(dedge), p(oh), p(orm),
+                                                      p(oam), st))
+    else:
+        F.check(F.lib().pcfit_fit_batch_dev(p(dx), p(dy), p(doff), S, mx, 1.0, 100, 1e-2, 1e-10, 1e-12, p(ok_),
+                                            p(of_), p(oi), p(os_), st))
+    torch.cuda.synchronize()
+    c = lambda a: a.cpu().numpy()
+    return dict(kasa=c(ok_), fit=c(of_), iters=c(oi), status=c(os_), hist=c(oh), rmm=c(orm), amm=c(oam))
+
+
+def test_fit_on_ragged_slices_of_up_to_8192_points():
+    """Batches whose longest slice has 4097..8192 points keep half of each slice in LDS: ragged lengths
+    (full groups and tails of every size, tiny and empty slices) and outliers beyond the Huber
+    threshold (the general form of the sweep)."""
+    gen = np.random.default_rng(11)
+    lens = np.concatenate([[8192, 4097, 8191, 4096, 5000, 0, 2, 3, 100, 1024, 2048, 6144, 7169],
+                           gen.integers(1, 8193, 600)])
+    S = len(lens)
+    x, y, _ = R.make_slices(1, int(lens.sum()), seed=6, outlier_frac=0.15, jitter=0.05)
+    off = np.zeros(S + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    H, lo, hi = 200, -0.4, 0.6
+    a = _fused_dev(x, y, off, H, lo, hi)
+    b = _fused_dev(x, y, off, H, lo, hi, want_resid=False)
+    for key in ("kasa", "fit", "iters", "status"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), key             # same passes, with and without residuals
+    k, st = F.kasa_batch(x, y, off)                                            # register / streaming kernels
+    fit, it = F.lm_batch(x, y, off, k)
+    ok = lens >= 3
+    assert np.array_equal(a["status"], st) and np.array_equal(a["status"] == 0, ok)
+    assert rel(a["kasa"][ok], k[ok]) < 1e-11
+    # (with outliers the cost is summed to ~1e-16 relative only, which leaves the point where the
+    # reference's own stopping rule triggers undetermined to ~1e-8: the same allowance as LM_TOL)
+    assert rel(a["fit"][ok], fit[ok]) < 1e-7
+    assert np.all(np.isnan(a["fit"][~ok])) and np.all(np.isnan(a["kasa"][~ok]))
+    assert np.mean(a["iters"][ok, 0] == it[ok, 0]) > 0.99                      # literal iteration counts
+    # the residual statistics are exact given the fitted circle
+    res = F.residuals_batch(x, y, off, a["fit"], bins=H, lo=lo, hi=hi, want_theta=False, want_dr=False)
+    assert np.array_equal(a["hist"][ok], res["hist"][ok])
+    assert np.array_equal(a["amm"][ok, 0], res["argmax"][ok]) and np.array_equal(a["amm"][ok, 1], res["argmin"][ok])
+    assert np.array_equal(a["rmm"][ok, 0], res["rmax"][ok]) and np.array_equal(a["rmm"][ok, 1], res["rmin"][ok])
+    for s in list(range(13)) + list(gen.choice(np.arange(13, S), 12, replace=False)):
+        if lens[s] < 3:
+            continue
+        sl = slice(off[s], off[s + 1])
+        so, ko = N.kasa(x[sl], y[sl])
+        assert rel(a["kasa"][s], ko) < 1e-11
+        lo_, _, _ = N.lm(x[sl], y[sl], ko)
+        assert rel(a["fit"][s], lo_) < 1e-7, s
+    again = _fused_dev(x, y, off, H, lo, hi)
+    for key in a:
+        assert np.array_equal(a[key], again[key], equal_nan=True), key          # bitwise reproducible
+
+
 def test_full_size_ransac_30pct_outliers():
     """10 000 slices x 8192 points, 30 % outliers, 1024 hypotheses: bit-exact consensus on 24 replayed slices."""
     S, n = 10_000, 8192
