@@ -2,10 +2,10 @@
 """Throughput of the fit + residual pass on MI355X.
 
 One step = one pass of the hot path over one batch of pre-binned slices that is
-already resident in HBM:  Kasa start + LM/Huber refinement (one launch,
-pcfit_fit_batch_dev, the slice held in registers) followed by the residual pass
-(pcfit_residuals_batch_dev: delta-r histogram of 256 bins over +-10 sigma,
-Rmax / Rmin and their indices).
+already resident in HBM, in ONE launch (pcfit_fit_residuals_batch_dev): Kasa
+start, LM/Huber refinement and the residual pass (delta-r histogram of 256 bins
+over +-10 sigma, Rmax / Rmin and their indices) with each slice read from HBM
+once and held on chip (half in registers, half in LDS) for all passes.
 Workload at N=1: 10 000 slices x 8192 points, FP64, synthetic noisy cylinder
 (the "1x MI355X batched algebraic+geometric fit" configuration).  With N > 1
 every rank owns its own batch of that size (slices shard with no data exchange;
@@ -32,13 +32,18 @@ sys.path.insert(0, ROOT)
 from pointcloud_amd import _ffi as F            # noqa: E402
 from pointcloud_amd.synth import make_slices    # noqa: E402
 
-# how the flop figure of the fit kernel is counted (per point and sweep): building the normal
-# equations = sqrt + divide (~15 flop each in Newton steps) + Jacobian + 9 weighted sums ~ 70 flop;
-# a candidate sweep adds compare, square and accumulate for the cost ~ 80 flop.  The reference's
-# literal loop does both computations separately in each of its 100 iterations (~1e4 flop/pt).
-FLOP_HG_PASS = 70.0     # sweep that builds the normal equations
-FLOP_COST_PASS = 80.0   # sweep that evaluates a candidate: the same plus the Huber cost
-FLOP_KASA = 20.0        # two passes: means, then seven centred sums
+# How the flop figure of the kernel is counted: the arithmetic of the short form of each pass, per
+# point, an FMA as 2, everything else (add, mul, compare, min, the hardware reciprocal square root) as 1.
+#   Kasa: sums (2) + centred moments (2 sub, 2 mul, 2 add, 5 fma)                               = 18
+#   LM sweep: distance (2 sub, mul, fma), rsqrt + 2 Newton steps (10), ri, 1/ri (5), residual and
+#             its test (2), Jacobian (2 mul), 7 fma + 3 add into H, g, cost, curvature, min (1)   = 42
+#   residuals: exact sum of squares (13), rsqrt + Newton (10), correctly rounded root (9), dr,
+#              extremes (5), bin guess and repair (8)                                             = 45
+# The reference's literal loop evaluates residuals and Jacobian separately in each of its 100
+# iterations (~1e4 flop per point); the kernel reaches the same accept/reject sequence in 3 sweeps.
+FLOP_KASA = 18.0
+FLOP_SWEEP = 42.0
+FLOP_RESID = 45.0
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
@@ -125,7 +130,7 @@ def main():
         g_hist = [torch.empty(world * S, H, dtype=torch.int32, device=dev) for _ in range(2)]
     pending = [None, None]
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    ev_fit, ev_res = [], []
+    ev_k = []
 
     def step(i, timed):
         b = i & 1
@@ -135,17 +140,13 @@ def main():
             pending[b] = None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e2 = torch.cuda.Event(enable_timing=True)
         e0.record()
-        F.check(L.pcfit_fit_batch_dev(ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa),
-                                      ptr(fit[b]), ptr(iters), ptr(status), stream))
+        F.check(L.pcfit_fit_residuals_batch_dev(ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12,
+                                                ptr(kasa), ptr(fit[b]), ptr(iters), ptr(status), H, ptr(edges),
+                                                ptr(hist), ptr(rmm), ptr(amm), stream))
         e1.record()
-        F.check(L.pcfit_residuals_batch_dev(ptr(x), ptr(y), ptr(off), S, ptr(fit[b]), None, None, None, H,
-                                            ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream))
-        e2.record()
         if timed:
-            ev_fit.append((e0, e1))
-            ev_res.append((e1, e2))
+            ev_k.append((e0, e1))
         if use_dist:
             hist32[b].copy_(hist)
             pending[b] = [dist.all_gather_into_tensor(g_fit[b], fit[b], async_op=True),
@@ -180,17 +181,18 @@ def main():
         dt = float(t.item())
 
     ms_step = dt / a.steps * 1e3
-    fit_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_fit]))
+    k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_k]))
     it = iters.cpu().numpy().astype(np.float64)
-    flop_launch = float(n * (FLOP_HG_PASS * it[:, 2].sum() + FLOP_COST_PASS * it[:, 3].sum() + FLOP_KASA * S))
-    res_bytes = float(S * n * 16)
-    res_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_res]))
+    sweeps = it[:, 2] + it[:, 3]
+    flop_launch = float(n * (FLOP_SWEEP * sweeps.sum() + (FLOP_KASA + FLOP_RESID) * S))
+    alg_bytes = float(S * n * 16)
 
     if rank == 0:
         traffic = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))
+        tf = flop_launch / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "points fitted/sec (circle fit+residuals)",
             "value": world * S * n / (dt / a.steps),
@@ -209,24 +211,22 @@ def main():
                        "slices_per_gpu": S, "points_per_slice": n, "hist_bins": H,
                        "parallelism": f"slice-sharded x{world}" + (", RCCL all-gather of fits+histograms" if world > 1 else "")},
             "roofline": {
-                "kernel": "fit_kernel<32,256> (Kasa + LM, slice in registers)",
+                "kernel": "fit_residual_kernel<16,16,256> (Kasa + LM + residuals, one read of the slice)",
                 "bound": "valu_fp64",
-                "achieved": flop_launch / (fit_ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                "frac": flop_launch / (fit_ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-                "traffic": traffic.get("fit_kernel_bytes"),
-                "avg_launch_ms": fit_ms,
+                "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+                "frac": tf / PEAK_FP64_VALU_TFLOPS,
+                "traffic": traffic.get("fit_residual_kernel_bytes"),
+                "avg_launch_ms": k_ms,
                 "flop_per_point": flop_launch / (S * n),
-                "mean_first_sweeps": float(it[:, 2].mean()), "mean_candidate_sweeps": float(it[:, 3].mean()),
-                "algorithmic_bytes": res_bytes,
-                "algorithmic_hbm_gbs": res_bytes / (fit_ms * 1e-3) / 1e9,
-                "hbm_frac": res_bytes / (fit_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "mean_sweeps": float(sweeps.mean()),
+                "algorithmic_bytes": alg_bytes,
             },
             "roofline_hbm": {
-                "kernel": "residuals_kernel", "bound": "hbm",
-                "achieved": res_bytes / (res_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": res_bytes / (res_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": traffic.get("residuals_kernel_bytes"),
-                "avg_launch_ms": res_ms,
+                "kernel": "fit_residual_kernel<16,16,256>", "bound": "hbm",
+                "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                "traffic": traffic.get("fit_residual_kernel_bytes"),
+                "avg_launch_ms": k_ms,
             },
         }
         if world == 1 and not a.no_cpu_baseline:
