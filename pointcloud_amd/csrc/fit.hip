@@ -73,25 +73,47 @@ struct SliceView {
     static constexpr int STRIDE = FIT_BLOCK;
     static constexpr int LDS_DOUBLES = 2 * PT_L * FIT_BLOCK;       // what the points take of lds_dyn
     const double *xs, *ys;
-    int64_t n;
+    int32_t n;
     double rx[PT_R > 0 ? PT_R : 1], ry[PT_R > 0 ? PT_R : 1];
 
     __device__ __forceinline__ void load(const double *x, const double *y, int64_t off, int64_t count)
     {
         xs = x + off;
         ys = y + off;
-        n = count;
-        if constexpr (!STREAM) {
-            if (n > (int64_t)(PT_R + PT_L) * FIT_BLOCK)
-                n = (int64_t)(PT_R + PT_L) * FIT_BLOCK;
-        }
-        // every load is unconditional (a point past the end reads the slice's last one and is then
-        // replaced by zero), so that all of them can be in flight together
-        const int64_t last = n > 0 ? n - 1 : 0;
-        if (n > 0) {
+        // n = min(count, what the storage holds), spelled with 32-bit compares: hipcc 7.2 turns the
+        // uniform 64-bit form of this clamp into a scalar select on a stale condition code
+        constexpr uint32_t CAP = STREAM ? 0x7fffffffu : (uint32_t)(PT_R + PT_L) * FIT_BLOCK;
+        const uint32_t hi = (uint32_t)((uint64_t)count >> 32), lo = (uint32_t)count;
+        n = (hi != 0 || lo > CAP) ? (int32_t)CAP : (int32_t)lo;
+        // Loads come first in a workgroup's life and the CU's other workgroup is usually in the middle of
+        // its arithmetic: raise the priority of these waves so that their loads get issued at once.
+        __builtin_amdgcn_s_setprio(3);
+        if (!STREAM && n == (PT_R + PT_L) * FIT_BLOCK) {
+            // a slice that fills the storage: nothing but loads, all in flight together
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
-                const int64_t i = threadIdx.x + k * FIT_BLOCK;
+                rx[k] = xs[threadIdx.x + k * FIT_BLOCK];
+                ry[k] = ys[threadIdx.x + k * FIT_BLOCK];
+            }
+            double tx[PT_L > 0 ? PT_L : 1], ty[PT_L > 0 ? PT_L : 1];
+#pragma unroll
+            for (int k = 0; k < PT_L; k++) {
+                tx[k] = xs[threadIdx.x + (PT_R + k) * FIT_BLOCK];
+                ty[k] = ys[threadIdx.x + (PT_R + k) * FIT_BLOCK];
+            }
+#pragma unroll
+            for (int k = 0; k < PT_L; k++) {
+                const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
+                lds_dyn[2 * j] = tx[k];
+                lds_dyn[2 * j + 1] = ty[k];
+            }
+        } else if (n > 0) {
+            // every load is unconditional (a point past the end reads the slice's last one and is then
+            // replaced by zero), so that all of them can be in flight together
+            const int32_t last = n - 1;
+#pragma unroll
+            for (int k = 0; k < PT_R; k++) {
+                const int32_t i = threadIdx.x + k * FIT_BLOCK;
                 const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
                 rx[k] = i < n ? vx : 0.0;
                 ry[k] = i < n ? vy : 0.0;
@@ -99,7 +121,7 @@ struct SliceView {
             // the LDS part travels through registers
 #pragma unroll
             for (int k = 0; k < PT_L; k++) {
-                const int64_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
+                const int32_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
                 const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
                 const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
                 lds_dyn[2 * j] = vx;
@@ -110,6 +132,7 @@ struct SliceView {
             for (int k = 0; k < PT_R; k++)
                 rx[k] = ry[k] = 0.0;
         }
+        __builtin_amdgcn_s_setprio(0);
         if constexpr (PT_L > 0)
             __syncthreads();
     }
@@ -119,14 +142,14 @@ struct SliceView {
     {
         constexpr int U = GROUP;
         if constexpr (STREAM) {
-            for (int64_t first = 0; first + U * FIT_BLOCK <= n; first += U * FIT_BLOCK) {
+            for (int32_t first = 0; first + U * FIT_BLOCK <= n; first += U * FIT_BLOCK) {
                 double px[U], py[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     px[u] = xs[first + u * FIT_BLOCK + threadIdx.x];
                     py[u] = ys[first + u * FIT_BLOCK + threadIdx.x];
                 }
-                fg(px, py, (int32_t)(first + threadIdx.x));
+                fg(px, py, first + (int32_t)threadIdx.x);
             }
         } else {
 #pragma unroll
@@ -144,7 +167,7 @@ struct SliceView {
             if constexpr (PT_L > 0) {
                 // a rolled loop with a uniform trip count; the pairs of the next trip are read before
                 // the current ones are worked on
-                const int32_t in_lds = (int32_t)n - PT_R * FIT_BLOCK;
+                const int32_t in_lds = n - PT_R * FIT_BLOCK;
                 const int32_t trips = in_lds > 0 ? in_lds / (U * FIT_BLOCK) : 0;
                 double qx[U], qy[U];
                 int32_t j = threadIdx.x;
@@ -178,14 +201,14 @@ struct SliceView {
     __device__ __forceinline__ void ragged_group(FG &&fg) const
     {
         constexpr int U = GROUP;
-        const int64_t first = n / (U * FIT_BLOCK) * (U * FIT_BLOCK);
+        const int32_t first = n / (U * FIT_BLOCK) * (U * FIT_BLOCK);
         if (first == n)
             return;
         double px[U], py[U];
         if constexpr (STREAM) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const int64_t i = first + u * FIT_BLOCK + threadIdx.x;
+                const int32_t i = first + u * FIT_BLOCK + (int32_t)threadIdx.x;
                 px[u] = xs[i < n - 1 ? i : n - 1];
                 py[u] = ys[i < n - 1 ? i : n - 1];
             }
@@ -205,7 +228,7 @@ struct SliceView {
             }
             if constexpr (PT_L > 0) {
                 if (first >= PT_R * FIT_BLOCK) {
-                    const int32_t j = (int32_t)first - PT_R * FIT_BLOCK + (int32_t)threadIdx.x;
+                    const int32_t j = first - PT_R * FIT_BLOCK + (int32_t)threadIdx.x;
 #pragma unroll
                     for (int u = 0; u < U; u++) {
                         px[u] = lds_dyn[2 * (j + u * FIT_BLOCK)];
@@ -214,7 +237,7 @@ struct SliceView {
                 }
             }
         }
-        fg(px, py, (int32_t)first + (int32_t)threadIdx.x);
+        fg(px, py, first + (int32_t)threadIdx.x);
     }
 };
 
@@ -740,26 +763,65 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
     const double scale = (double)H / (eH - e0);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     Extreme2 mx{-inf, -1}, mn{inf, -1};
-    // (no branch in the body but the one around the counter update, so that the points of a group interleave)
-    each_point(P, [&](double px, double py, int32_t i, bool valid) {
-        const double r = cr_hypot(px - cx, py - cy);
-        const double d = r - R;
-        const bool up = valid && r > mx.r, dn = valid && r < mn.r;      // strict: the first index of an extreme value stays
-        mx.r = up ? r : mx.r;
-        mx.i = up ? i : mx.i;
-        mn.r = dn ? r : mn.r;
-        mn.i = dn ? i : mn.i;
-        if (H > 0) {
-            // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
-            const bool in = valid && d >= e0 && d <= eH;
-            int32_t b = (int32_t)((d - e0) * scale);
-            b = b < 0 ? 0 : (b > H - 1 ? H - 1 : b);
-            const double below = lds_dyn[base + b], above = lds_dyn[base + b + 1];
-            b += d < below ? -1 : ((b < H - 1 && d >= above) ? 1 : 0);
-            if (in)
-                atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + base + H + 1) + b, 1);
+    // A group of U points: everything up to the bin numbers is computed for all of them without a
+    // branch, so that their dependency chains interleave; the counter updates come last.  HIST and
+    // CHECK (points past the end of the slice do not count) are compile-time so that the pass over the
+    // full groups carries neither test.
+    constexpr int U = View::GROUP;
+    auto pass = [&](const double (&px)[U], const double (&py)[U], int32_t i0, auto hist_tag, auto check_tag) {
+        constexpr bool HIST = decltype(hist_tag)::value, CHECK = decltype(check_tag)::value;
+        double r[U];
+        bool valid[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            r[u] = cr_hypot(px[u] - cx, py[u] - cy);
+            valid[u] = !CHECK || i0 + u * View::STRIDE < P.n;
         }
-    });
+        int32_t b[U];
+        bool in[U];
+        if constexpr (HIST) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
+                const double d = r[u] - R;
+                in[u] = valid[u] & (d >= e0) & (d <= eH);
+                const int32_t guess = (int32_t)((d - e0) * scale);
+                const int32_t g = max(0, min(guess, H - 1));
+                const double below = lds_dyn[base + g], above = lds_dyn[base + g + 1];
+                const bool under = d < below, over = !under & (g < H - 1) & (d >= above);
+                b[u] = g + (over ? 1 : 0) - (under ? 1 : 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int32_t i = i0 + u * View::STRIDE;
+            const bool up = valid[u] & (r[u] > mx.r), dn = valid[u] & (r[u] < mn.r);   // strict: the first index stays
+            if constexpr (CHECK) {
+                mx.r = up ? r[u] : mx.r;
+                mn.r = dn ? r[u] : mn.r;
+            } else {
+                mx.r = max_no_nan(mx.r, r[u]);
+                mn.r = min_no_nan(mn.r, r[u]);
+            }
+            mx.i = up ? i : mx.i;
+            mn.i = dn ? i : mn.i;
+        }
+        if constexpr (HIST) {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (in[u])
+                    atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + base + H + 1) + b[u], 1);
+        }
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    if (H > 0) {
+        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, Yes{}, No{}); });
+        P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, Yes{}, Yes{}); });
+    } else {
+        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, No{}, No{}); });
+        P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, No{}, Yes{}); });
+    }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         Extreme2 o;
@@ -808,6 +870,7 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
     P.load(x, y, off, n);
+    ph.mark(0);
     constexpr int base = SliceView<PT_R, PT_L, FIT_BLOCK>::LDS_DOUBLES;
     for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
         reinterpret_cast<int32_t *>(lds_dyn + base + H + 1)[b] = 0;
@@ -820,11 +883,13 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
         kasa_out[3 * s + 1] = c[1];
         kasa_out[3 * s + 2] = c[2];
     }
+    ph.mark(1);
     int32_t it[4] = {0, 0, 0, 0};
     if (st != PCFIT_ST_SPARSE)
         lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
     __syncthreads();
     residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin);
+    ph.mark(5);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -854,6 +919,7 @@ static FitShape pick_shape(int64_t max_len)
     if (max_len <= 1024) return {256, 4, 0};
     if (max_len <= 2048) return {256, 8, 0};
     if (max_len <= 4096) return {256, 16, 0};
+    // (512 threads with 8 + 8 points each, four waves per SIMD at 128 VGPRs, measured 20 % slower)
     if (max_len <= 8192) return {256, 16, 16};
     return {256, 0, 0};
 }

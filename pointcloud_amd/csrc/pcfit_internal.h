@@ -208,11 +208,19 @@ constexpr int rs_lowmask()
         return M >= 1 ? 2 * M - 1 : 0;
 }
 
-// the smaller of two numbers, neither a NaN: one instruction (fmin() first quiets its operands)
+// the smaller / larger of two numbers, neither a signalling NaN: one instruction (fmin() and fmax() first
+// quiet their operands); a quiet NaN operand yields the other one
 __device__ __forceinline__ double min_no_nan(double a, double b)
 {
     double r;
     asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ double max_no_nan(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 

@@ -34,6 +34,10 @@ if os.environ.get("ONLY") == "fused":
     torch.cuda.synchronize()
     sys.exit(0)
 timeit("fit (kasa+lm)", lambda: F.check(L.pcfit_fit_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), st)))
+for mi in (100,):
+    timeit(f"fit max_iter={mi}", lambda: F.check(L.pcfit_fit_batch_dev(p(x), p(y), p(off), S, n, 1.0, mi, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), st)))
+    print("   sweeps", iters[0].tolist())
+timeit("kasa only", lambda: F.check(L.pcfit_kasa_batch_dev(p(x), p(y), p(off), S, n, p(kasa), p(status), st)))
 timeit("fit+residuals fused", lambda: F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st)))
 if os.environ.get("PHASES"):
     out = (C.c_int64 * 16)()
@@ -42,7 +46,7 @@ if os.environ.get("PHASES"):
     F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st))
     torch.cuda.synchronize()
     L2.pcfit_debug_phase_clocks(out, 0)
-    names = ["stage/switch", "kasa", "sweep points", "sweep reduce", "lm serial", "residual+out"]
+    names = ["load", "kasa", "sweep points (+solve)", "sweep reduce", "lm end", "residual"]
     tot = sum(out[:6])
     for k, nm in enumerate(names):
         print(f"   phase {nm:14s} {out[k]/S:10.0f} clk/slice  {100*out[k]/max(tot,1):5.1f} %")
