@@ -69,7 +69,7 @@ template <int PT_R, int PT_L, int FIT_BLOCK>
 struct SliceView {
     static constexpr bool STREAM = PT_R == 0 && PT_L == 0;
     // (with 64 VGPRs of points per thread a group of 4 no longer fits the register file beside them)
-    static constexpr int GROUP = PT_R >= 16 ? 2 : ((STREAM || (PT_R % 4 == 0 && PT_L % 4 == 0)) ? 4 : 1);
+    static constexpr int GROUP = (STREAM || (PT_R % 4 == 0 && PT_L % 4 == 0)) ? 4 : 1;
     static constexpr int STRIDE = FIT_BLOCK;
     static constexpr int LDS_DOUBLES = 2 * PT_L * FIT_BLOCK;       // what the points take of lds_dyn
     const double *xs, *ys;
@@ -136,6 +136,9 @@ struct SliceView {
         if constexpr (PT_L > 0)
             __syncthreads();
     }
+
+    // how many points full_groups() hands to each thread
+    __device__ __forceinline__ int32_t full_points_per_thread() const { return n / (GROUP * FIT_BLOCK) * GROUP; }
 
     template <class FG>
     __device__ __forceinline__ void full_groups(FG &&fg) const
@@ -500,7 +503,7 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
             for (int k = 0; k < 12; k++)
                 acc[k] = 0.0;
             low = inf;
-            bool odd = false;
+            double amax = 0.0;                  // largest |residual| seen
             P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -510,7 +513,7 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
                     const double ri = fma(d2, y0, 1e-16);
                     const double iv = fma(-1e-16 * y0, y0, y0);
                     const double r = ri - pr;
-                    odd |= !(fabs(r) <= delta);          // also true for the NaN a zero distance gives here
+                    amax = max_abs_no_nan(amax, r);
                     const double j0 = -dx * iv, j1 = -dy * iv;
                     acc[10] = fma(r, r, acc[10]);
                     acc[0] = fma(j0, j0, acc[0]);
@@ -518,7 +521,6 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
                     acc[2] = acc[2] - j0;
                     acc[3] = fma(j1, j1, acc[3]);
                     acc[4] = acc[4] - j1;
-                    acc[5] = acc[5] + 1.0;
                     acc[6] = fma(j0, r, acc[6]);
                     acc[7] = fma(j1, r, acc[7]);
                     acc[8] = acc[8] - r;
@@ -526,6 +528,10 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
                     low = min_no_nan(low, ri);
                 }
             });
+            // a point was not regular: a residual beyond the threshold, or a NaN (which a distance of
+            // zero gives here as well) that the sum of squares has kept
+            const bool odd = !(amax <= delta) || acc[10] != acc[10];
+            acc[5] = (double)P.full_points_per_thread();      // the sum of that many ones (j2 = -1)
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);

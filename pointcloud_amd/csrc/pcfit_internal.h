@@ -224,6 +224,14 @@ __device__ __forceinline__ double max_no_nan(double a, double b)
     return r;
 }
 
+// max(a, |b|), same remarks
+__device__ __forceinline__ double max_abs_no_nan(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ double wave_min(double v)
 {
 #pragma unroll
@@ -278,14 +286,14 @@ __device__ __forceinline__ double wrap_angle(double dy, double dx)
     return fmod(atan2(dy, dx) + TWO_PI, TWO_PI);
 }
 
-// 1/sqrt(d) to about one ulp: hardware estimate plus two Newton steps (d > 0, normal range)
+// 1/sqrt(d) to about one ulp (d > 0, normal range): the hardware estimate is good to 2^-24 (measured,
+// tools/ubench/rsq_acc.hip), so one third-order step, y' = y + y e (1/2 + 3/8 e) with e = 1 - d y^2, leaves
+// an error of 1.4e-16 at most - below that of two Newton steps (2.4e-16) at five operations instead of seven.
 __device__ __forceinline__ double rsqrt_nr(double d)
 {
-    double y = __builtin_amdgcn_rsq(d);
-    const double h = 0.5 * d;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
+    const double y = __builtin_amdgcn_rsq(d);
+    const double e = fma(-d * y, y, 1.0);
+    return fma(y * e, fma(0.375, e, 0.5), y);
 }
 
 // hypot(x, y) rounded to nearest.  The sum of squares is formed exactly as a
