@@ -75,6 +75,7 @@ struct SliceView {
     const double *xs, *ys;
     int32_t n;
     double rx[PT_R > 0 ? PT_R : 1], ry[PT_R > 0 ? PT_R : 1];
+    double sum_x, sum_y;        // this thread's share of the coordinate sums, taken while loading (not STREAM)
 
     __device__ __forceinline__ void load(const double *x, const double *y, int64_t off, int64_t count)
     {
@@ -88,6 +89,7 @@ struct SliceView {
         // Loads come first in a workgroup's life and the CU's other workgroup is usually in the middle of
         // its arithmetic: raise the priority of these waves so that their loads get issued at once.
         __builtin_amdgcn_s_setprio(3);
+        sum_x = sum_y = 0.0;
         if (!STREAM && n == (PT_R + PT_L) * FIT_BLOCK) {
             // a slice that fills the storage: nothing but loads, all in flight together
 #pragma unroll
@@ -107,6 +109,16 @@ struct SliceView {
                 lds_dyn[2 * j] = tx[k];
                 lds_dyn[2 * j + 1] = ty[k];
             }
+#pragma unroll
+            for (int k = 0; k < PT_R; k++) {
+                sum_x += rx[k];
+                sum_y += ry[k];
+            }
+#pragma unroll
+            for (int k = 0; k < PT_L; k++) {
+                sum_x += tx[k];
+                sum_y += ty[k];
+            }
         } else if (n > 0) {
             // every load is unconditional (a point past the end reads the slice's last one and is then
             // replaced by zero), so that all of them can be in flight together
@@ -117,6 +129,8 @@ struct SliceView {
                 const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
                 rx[k] = i < n ? vx : 0.0;
                 ry[k] = i < n ? vy : 0.0;
+                sum_x += rx[k];
+                sum_y += ry[k];
             }
             // the LDS part travels through registers
 #pragma unroll
@@ -126,6 +140,8 @@ struct SliceView {
                 const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
                 lds_dyn[2 * j] = vx;
                 lds_dyn[2 * j + 1] = vy;
+                sum_x += i < n ? vx : 0.0;
+                sum_y += i < n ? vy : 0.0;
             }
         } else {
 #pragma unroll
@@ -286,10 +302,15 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
     double s1[2] = {0.0, 0.0};
-    each_point(P, [&](double px, double py, int32_t, bool valid) {
-        s1[0] += valid ? px : 0.0;
-        s1[1] += valid ? py : 0.0;
-    });
+    if constexpr (View::STREAM) {
+        each_point(P, [&](double px, double py, int32_t, bool valid) {
+            s1[0] += valid ? px : 0.0;
+            s1[1] += valid ? py : 0.0;
+        });
+    } else {
+        s1[0] = P.sum_x;            // summed in the same order while the slice was loaded
+        s1[1] = P.sum_y;
+    }
     double *tot = red.totals(0);
     block_reduce_to_lds<2, false, NW>(s1, 0.0, red.scratch(), tot);
     const double mx = tot[0] / n, my = tot[1] / n;
