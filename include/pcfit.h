@@ -128,6 +128,41 @@ int pcfit_fit_residuals_batch_dev(const double *x, const double *y, const int64_
                                   int32_t *status, int32_t n_bins, const double *edges, int64_t *hist,
                                   double *rmax_rmin, int64_t *argmax_argmin, void *stream);
 
+/* ---- the same fits and statistics for LONG slices ------------------------
+ * The entry points above give a slice to one workgroup, which fills the GPU
+ * when there are many slices.  These cut every slice into segments of 8192
+ * points (one workgroup each) and combine the partial results per slice in a
+ * fixed order, so a scan of a few dozen windows of a million points each also
+ * uses the whole chip.  Same arguments and results as their namesakes
+ * (fit_circle_pratt circle_fitting.py:35-54, lm_circle_geometric :57-109, the
+ * residual statistics analyzer.py:83-92 / gui.py:972-987, boundary_by_angle_max
+ * boundary.py:7-42); sums are taken in another order, so fitted parameters agree
+ * to rounding (~1e-15), integer results exactly.  total_points = offsets[n_slices].
+ * workspace: pcfit_split_workspace_bytes(total_points, n_slices, bins) bytes of
+ * device memory (bins = 0 unless pcfit_angle_max_split_dev is called).
+ * pcfit_lm_split_dev enqueues max_iter + 1 rounds of two launches; slices that
+ * have finished cost next to nothing in the later rounds. */
+size_t pcfit_split_workspace_bytes(int64_t total_points, int64_t n_slices, int32_t n_bins);
+int pcfit_kasa_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                         int64_t total_points, double *cxcyr, int32_t *status, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int pcfit_lm_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                       int64_t total_points, const double *init, double huber_delta, int32_t max_iter,
+                       double lm_lambda0, double tol_update, double tol_cost, double *out, int32_t *iters,
+                       void *workspace, size_t workspace_bytes, void *stream);
+/* Kasa start then LM; kasa_out, out and status are required here. */
+int pcfit_fit_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                        int64_t total_points, double huber_delta, int32_t max_iter, double lm_lambda0,
+                        double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
+                        int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int pcfit_residuals_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                              int64_t total_points, const double *cxcyr, double *theta, double *dr, double *radius,
+                              int32_t n_bins, const double *edges, int64_t *hist, double *rmax_rmin,
+                              int64_t *argmax_argmin, void *workspace, size_t workspace_bytes, void *stream);
+int pcfit_angle_max_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                              int64_t total_points, const double *cxcyr, int32_t bins, int64_t *sel,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- RANSAC: _ransac_circle, circle_fitting.py:112-143 --------------- */
 /* triples: n_tables tables of trials*3 int32 (pcfit_choice3_table), device
  * memory; table_of_slice[s] selects the table built for that slice's n.

@@ -53,6 +53,15 @@ SIGNATURES = {
                                       _vp]),
     "pcfit_fit_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp,
                                                 _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pcfit_split_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "pcfit_kasa_split_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pcfit_lm_split_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _sz,
+                                     _vp]),
+    "pcfit_fit_split_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp, _vp,
+                                      _sz, _vp]),
+    "pcfit_residuals_split_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp,
+                                            _vp, _sz, _vp]),
+    "pcfit_angle_max_split_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i32, _vp, _vp, _sz, _vp]),
     "pcfit_ransac_workspace_bytes": (_sz, [_i64]),
     "pcfit_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _sz, _vp]),

@@ -211,6 +211,9 @@ namespace pcfit {
 int launch_kasa(const double *, const double *, const int64_t *, int64_t, int64_t, double *, int32_t *, hipStream_t);
 }
 
+// Host-pointer calls hand batches whose longest slice exceeds this to the segment-parallel kernels.
+static constexpr int64_t LONG_SLICE = 8192;
+
 PCFIT_API int pcfit_kasa_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                double *cxcyr, int32_t *status)
 {
@@ -225,6 +228,17 @@ PCFIT_API int pcfit_kasa_batch(const double *x, const double *y, const int64_t *
     PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
     PCFIT_TRY(dout.alloc(n_slices * 24));
     PCFIT_TRY(dst.alloc(n_slices * 4));
+    if (max_len > LONG_SLICE) {
+        DevBuf dws;
+        const size_t wsb = pcfit_split_workspace_bytes(total, n_slices, 0);
+        PCFIT_TRY(dws.alloc(wsb));
+        PCFIT_TRY(pcfit_kasa_split_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, total,
+                                       dout.as<double>(), dst.as<int32_t>(), dws.p, wsb, st));
+        PCFIT_TRY(dout.download(cxcyr, n_slices * 24, st));
+        PCFIT_TRY(dst.download(status, n_slices * 4, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+        return PCFIT_OK;
+    }
     PCFIT_TRY(launch_kasa(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
                           dout.as<double>(), dst.as<int32_t>(), st));
     PCFIT_TRY(dout.download(cxcyr, n_slices * 24, st));
@@ -249,9 +263,18 @@ PCFIT_API int pcfit_lm_batch(const double *x, const double *y, const int64_t *of
     PCFIT_TRY(dinit.upload(init, n_slices * 24, st));
     PCFIT_TRY(dout.alloc(n_slices * 24));
     PCFIT_TRY(dit.alloc(n_slices * 16));
-    PCFIT_TRY(pcfit_lm_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
-                                 dinit.as<double>(), huber_delta, max_iter, lm_lambda0, tol_update, tol_cost,
-                                 dout.as<double>(), dit.as<int32_t>(), st));
+    DevBuf dws;
+    if (max_len > LONG_SLICE) {
+        const size_t wsb = pcfit_split_workspace_bytes(total, n_slices, 0);
+        PCFIT_TRY(dws.alloc(wsb));
+        PCFIT_TRY(pcfit_lm_split_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, total,
+                                     dinit.as<double>(), huber_delta, max_iter, lm_lambda0, tol_update, tol_cost,
+                                     dout.as<double>(), dit.as<int32_t>(), dws.p, wsb, st));
+    } else {
+        PCFIT_TRY(pcfit_lm_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
+                                     dinit.as<double>(), huber_delta, max_iter, lm_lambda0, tol_update, tol_cost,
+                                     dout.as<double>(), dit.as<int32_t>(), st));
+    }
     PCFIT_TRY(dout.download(out, n_slices * 24, st));
     PCFIT_TRY(dit.download(iters, n_slices * 16, st));
     PCFIT_HIP(hipStreamSynchronize(st));
@@ -334,10 +357,20 @@ PCFIT_API int pcfit_residuals_batch(const double *x, const double *y, const int6
     }
     PCFIT_TRY(drm.alloc(n_slices * 16));
     PCFIT_TRY(dam.alloc(n_slices * 16));
-    PCFIT_TRY(pcfit_residuals_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
-                                        dfit.as<double>(), dth.as<double>(), ddr.as<double>(), drad.as<double>(), n_bins,
-                                        dedge.as<double>(), dhist.as<int64_t>(), drm.as<double>(), dam.as<int64_t>(),
-                                        st));
+    DevBuf dws;
+    if (max_len > LONG_SLICE) {
+        const size_t wsb = pcfit_split_workspace_bytes(total, n_slices, 0);
+        PCFIT_TRY(dws.alloc(wsb));
+        PCFIT_TRY(pcfit_residuals_split_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, total,
+                                            dfit.as<double>(), dth.as<double>(), ddr.as<double>(), drad.as<double>(),
+                                            n_bins, dedge.as<double>(), dhist.as<int64_t>(), drm.as<double>(),
+                                            dam.as<int64_t>(), dws.p, wsb, st));
+    } else {
+        PCFIT_TRY(pcfit_residuals_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
+                                            dfit.as<double>(), dth.as<double>(), ddr.as<double>(), drad.as<double>(),
+                                            n_bins, dedge.as<double>(), dhist.as<int64_t>(), drm.as<double>(),
+                                            dam.as<int64_t>(), st));
+    }
     if (theta) PCFIT_TRY(dth.download(theta, total * 8, st));
     if (dr) PCFIT_TRY(ddr.download(dr, total * 8, st));
     if (radius) PCFIT_TRY(drad.download(radius, total * 8, st));
@@ -363,8 +396,16 @@ PCFIT_API int pcfit_angle_max_batch(const double *x, const double *y, const int6
     PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
     PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
     PCFIT_TRY(dsel.alloc((size_t)n_slices * (bins > 0 ? bins : 1) * 8));
-    PCFIT_TRY(pcfit_angle_max_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
-                                        dfit.as<double>(), bins, dsel.as<int64_t>(), st));
+    DevBuf dws;
+    if (max_len > LONG_SLICE && bins >= 1) {
+        const size_t wsb = pcfit_split_workspace_bytes(total, n_slices, bins);
+        PCFIT_TRY(dws.alloc(wsb));
+        PCFIT_TRY(pcfit_angle_max_split_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, total,
+                                            dfit.as<double>(), bins, dsel.as<int64_t>(), dws.p, wsb, st));
+    } else {
+        PCFIT_TRY(pcfit_angle_max_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
+                                            dfit.as<double>(), bins, dsel.as<int64_t>(), st));
+    }
     PCFIT_TRY(dsel.download(sel, (size_t)n_slices * bins * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     return PCFIT_OK;

@@ -21,6 +21,8 @@
 // look-ups for points that are clearly interior.
 // HBM traffic: 24 B/point read in count, 24 B read + 16 B (+8 B perm) written
 // in scatter.
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -196,12 +198,13 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
                                                         double *__restrict__ x_out, double *__restrict__ y_out,
                                                         int64_t *__restrict__ perm)
 {
-    extern __shared__ int64_t cursor[];
+    // cursor[s]: where this wave's next member of window s goes, relative to the window's first slot
+    extern __shared__ uint32_t cursor[];
     const int64_t c = blockIdx.x;
     const int lane = threadIdx.x;
     const uint64_t below = (1ull << lane) - 1ull;
     for (int64_t s = lane; s < g.S; s += 64)
-        cursor[s] = offsets[s] + segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s];
+        cursor[s] = (uint32_t)(segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s]);
     __syncthreads();
     const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
     for (int64_t base = begin; base < end; base += 64) {
@@ -224,9 +227,10 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
         if (twice == 0ull) {
             if (k1 >= 0) {
                 const int rank = __popcll(same & below), cnt = __popcll(same);
-                const int64_t at = cursor[k1];
+                const uint32_t rel = cursor[k1];
                 if (rank == cnt - 1)
-                    cursor[k1] = at + cnt;
+                    cursor[k1] = rel + cnt;
+                const int64_t at = offsets[k1] + rel;
                 x_out[at + rank] = px;
                 y_out[at + rank] = py;
                 if (perm) perm[at + rank] = i;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
                 const uint64_t grp1 = same | (key >= 2u ? from_prev : 0ull);
                 rank1 = __popcll(grp1 & below);
                 cnt1 = __popcll(grp1);
-                at1 = cursor[k1];
+                at1 = cursor[k1];               // (relative; the window's first slot is added below)
                 if (has2) {
                     const uint64_t grp2 = to_next | (same & twice);
                     rank2 = __popcll(grp2 & below);
@@ -252,9 +256,12 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
             // all reads of the cursors precede the writes (one wave, LDS ops in order)
             if (k1 >= 0) {
                 if (rank1 == cnt1 - 1)
-                    cursor[k1] = at1 + cnt1;
+                    cursor[k1] = (uint32_t)(at1 + cnt1);
                 if (has2 && rank2 == cnt2 - 1)
-                    cursor[k1 + 1] = at2 + cnt2;
+                    cursor[k1 + 1] = (uint32_t)(at2 + cnt2);
+                at1 += offsets[k1];
+                if (has2)
+                    at2 += offsets[k1 + 1];
                 x_out[at1 + rank1] = px;
                 y_out[at1 + rank1] = py;
                 if (perm) perm[at1 + rank1] = i;
@@ -278,7 +285,8 @@ static BinPlan bin_plan(int64_t n, int64_t S)
     BinPlan p;
     const int64_t Sg = std::max<int64_t>(S, 1);
     int64_t chunks = std::max<int64_t>(1, (n + 4095) / 4096);
-    chunks = std::min<int64_t>(chunks, std::min<int64_t>(2048, std::max<int64_t>(1, (16ll << 20) / Sg)));
+    static const int64_t cap = [] { const char *e = getenv("PCFIT_BIN_CHUNKS"); return e ? atoll(e) : 2048ll; }();
+    chunks = std::min<int64_t>(chunks, std::min<int64_t>(cap, std::max<int64_t>(1, (32ll << 20) / Sg)));
     int64_t len = (n + chunks - 1) / std::max<int64_t>(chunks, 1);
     len = std::max<int64_t>(64, (len + 63) / 64 * 64);
     chunks = std::max<int64_t>(1, (n + len - 1) / len);
@@ -379,7 +387,7 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     int nbits = 1;
     while ((1ll << nbits) < n_slices + 2)
         nbits++;
-    bin_scatter_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 8, st>>>(
+    bin_scatter_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
         xyz, n_points, p.chunk_len, z_lo, z_hi, g, nbits, counts, segsum, offsets, x_out, y_out, perm);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;

@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "pcfit_internal.h"
+#include "fit_math.h"
 
 namespace pcfit {
 
@@ -331,104 +332,8 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
 #pragma unroll
     for (int k = 0; k < 7; k++)
         m[k] = tot[k];
-    const double a = 2 * m[0], b = 2 * m[2], d = 2 * m[1];
-    const double r0 = m[3] + m[5], r1 = m[4] + m[6];
-    double uc, vc;
-    const double det = solve2x2(a, b, r0, b, d, r1, uc, vc);
-    int st = PCFIT_ST_OK;
-    if (det == 0.0 || !isfinite(uc) || !isfinite(vc)) {
-        // exactly singular normal equations (the reference then takes the
-        // minimum-norm least-squares solution, circle_fitting.py:50-51)
-        st = PCFIT_ST_SINGULAR;
-        const double tr = a + d;
-        if (!(tr > 0.0)) {
-            uc = vc = 0.0;
-        } else {
-            // rank one: A = lam * w w^T with w the dominant eigenvector
-            double wx, wy;
-            if (a >= d) { wx = a; wy = b; } else { wx = b; wy = d; }
-            const double nw = sqrt(wx * wx + wy * wy);
-            wx /= nw;
-            wy /= nw;
-            const double lam = wx * (a * wx + b * wy) + wy * (b * wx + d * wy);
-            const double proj = (wx * r0 + wy * r1) / lam;
-            uc = wx * proj;
-            vc = wy * proj;
-        }
-    }
-    out[0] = mx + uc;
-    out[1] = my + vc;
-    out[2] = sqrt(uc * uc + vc * vc + (m[0] + m[1]) / n);
-    return st;
+    return kasa_from_moments(m, mx, my, n, out);
 }
-
-// 3x3 Gaussian elimination with partial pivoting (first largest entry of the
-// column, as LAPACK's pivot search); false on an exactly zero pivot.  Row swaps
-// are selects and each pivot is inverted once (Newton-refined reciprocal), as
-// LAPACK scales a pivot column, so the whole solve is a short branch-free chain:
-// every thread of the workgroup runs it between two sweeps.
-__device__ __forceinline__ double rcp_nr(double a)
-{
-    double y = __builtin_amdgcn_rcp(a);
-    double e = fma(-a, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-a, y, 1.0);
-    return fma(y, e, y);
-}
-
-__device__ __forceinline__ void swap_if(bool c, double &a, double &b)
-{
-    const double t = c ? b : a;
-    b = c ? a : b;
-    a = t;
-}
-
-__device__ __forceinline__ bool solve3x3(double A[3][3], double b[3], double x[3])
-{
-    // column 0
-    const bool p1 = fabs(A[1][0]) > fabs(A[0][0]);
-    const bool p2 = fabs(A[2][0]) > fmax(fabs(A[0][0]), fabs(A[1][0]));
-    const bool s1 = p1 && !p2;
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        swap_if(s1, A[0][j], A[1][j]);
-        swap_if(p2, A[0][j], A[2][j]);
-    }
-    swap_if(s1, b[0], b[1]);
-    swap_if(p2, b[0], b[2]);
-    if (A[0][0] == 0.0)
-        return false;
-    const double i0 = rcp_nr(A[0][0]);
-    const double l1 = A[1][0] * i0, l2 = A[2][0] * i0;
-    A[1][1] -= l1 * A[0][1];
-    A[1][2] -= l1 * A[0][2];
-    b[1] -= l1 * b[0];
-    A[2][1] -= l2 * A[0][1];
-    A[2][2] -= l2 * A[0][2];
-    b[2] -= l2 * b[0];
-    // column 1
-    const bool q = fabs(A[2][1]) > fabs(A[1][1]);
-    swap_if(q, A[1][1], A[2][1]);
-    swap_if(q, A[1][2], A[2][2]);
-    swap_if(q, b[1], b[2]);
-    if (A[1][1] == 0.0)
-        return false;
-    const double i1 = rcp_nr(A[1][1]);
-    const double l = A[2][1] * i1;
-    A[2][2] -= l * A[1][2];
-    b[2] -= l * b[1];
-    if (A[2][2] == 0.0)
-        return false;
-    x[2] = b[2] * rcp_nr(A[2][2]);
-    x[1] = (b[1] - A[1][2] * x[2]) * i1;
-    x[0] = (b[0] - A[0][1] * x[1] - A[0][2] * x[2]) * i0;
-    return true;
-}
-
-struct LmParams {
-    double delta, lam0, tol_update, tol_cost;
-    int32_t max_iter;
-};
 
 // circle_fitting.py:80-109.  Every accept / reject decision is the reference's
 // (cost of the candidate against the last accepted cost).  Two things the
@@ -452,9 +357,7 @@ template <int NW, class View>
 __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedCtx &red, double par[3],
                                          int32_t iters[4], Phase &ph)
 {
-    double cx = par[0], cy = par[1], rad = par[2];
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    double lam = prm.lam0, prev = inf;
     const double delta = prm.delta;
     const double root_delta = sqrt(delta);
     // One sweep over the points at parameters (px0, py0, pr): the normal equations H, g of the
@@ -477,46 +380,9 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
         double low;
         auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
 #pragma unroll
-            for (int u = 0; u < U; u++) {
-                const bool valid = !check || i0 + u * View::STRIDE < P.n;
-                const double dx = px[u] - px0, dy = py[u] - py0;
-                const double d2 = fma(dx, dx, dy * dy);
-                const bool pos = d2 > 0.0;
-                // ri = sqrt(d2) + 1e-16 and 1/ri (first order in the 1e-16)
-                const double y0 = rsqrt_nr(d2);
-                const double y = pos ? y0 : 0.0;
-                const double ri = fma(d2, y, 1e-16);
-                const double iv = pos ? fma(-1e-16 * y0, y0, y0) : 1e16;
-                const double res = ri - pr;
-                const double a = fabs(res);
-                const bool big = a > delta;
-                const double sw = root_delta * rsqrt_nr(a + 1e-16);      // sqrt(delta / (a + 1e-16))
-                double j0 = -dx * iv, j1 = -dy * iv;
-                j0 = big ? j0 * sw : j0;
-                j1 = big ? j1 * sw : j1;
-                double j2 = big ? -sw : -1.0;
-                double rw = big ? res * sw : res;
-                double psi = big ? delta : a;
-                j0 = valid ? j0 : 0.0;
-                j1 = valid ? j1 : 0.0;
-                j2 = valid ? j2 : 0.0;
-                rw = valid ? rw : 0.0;
-                psi = valid ? psi : 0.0;
-                const double c11 = fma(delta, a - 0.5 * delta, acc[11]), c10 = fma(a, a, acc[10]);
-                acc[11] = (valid && big) ? c11 : acc[11];
-                acc[10] = (valid && !big) ? c10 : acc[10];
-                acc[0] = fma(j0, j0, acc[0]);
-                acc[1] = fma(j0, j1, acc[1]);
-                acc[2] = fma(j0, j2, acc[2]);
-                acc[3] = fma(j1, j1, acc[3]);
-                acc[4] = fma(j1, j2, acc[4]);
-                acc[5] = fma(j2, j2, acc[5]);
-                acc[6] = fma(j0, rw, acc[6]);
-                acc[7] = fma(j1, rw, acc[7]);
-                acc[8] = fma(j2, rw, acc[8]);
-                acc[9] = fma(psi, iv, acc[9]);
-                low = valid ? fmin(low, ri) : low;
-            }
+            for (int u = 0; u < U; u++)
+                lm_point_general(acc, low, px[u], py[u], px0, py0, pr, delta, root_delta,
+                                 !check || i0 + u * View::STRIDE < P.n);
         };
         auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, true); };
         if (!general) {
@@ -573,96 +439,15 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
         ph.mark(3);
     };
 
-    int cur = -1;                               // which totals area holds H, g at (cx, cy, rad); none yet
-    const double *hg = red.totals(0);
-    double min_ri = 0.0;
-    double tx = cx, ty = cy, tr = rad;          // what the next sweep evaluates: first the start itself
-    double step[3] = {0.0, 0.0, 0.0};
-    bool first = true;
-    int32_t it = 0, acc_steps = 0, n_first = 0, n_sweeps = 0;
     // (one call site for the sweep: its body is the bulk of the kernel's code)
-    while (prm.max_iter > 0) {
-        const int into = cur == 0 ? 1 : 0;      // never the area the current H, g live in
-        const double *trial = red.totals(into);
-        sweep(tx, ty, tr, red.totals(into));
-        bool adopt, done = false;
-        if (first) {
-            // H and g at the start; its cost is not used (the reference starts from cost_prev = inf)
-            first = false;
-            adopt = true;
-            n_first++;
-        } else {
-            n_sweeps++;
-            const double cost = 0.5 * trial[10] + trial[11];
-            if (cost < prev - prm.tol_cost) {
-                cx = tx;
-                cy = ty;
-                rad = tr;
-                prev = cost;
-                lam = lam / 3 > 1e-12 ? lam / 3 : 1e-12;
-                acc_steps++;
-                adopt = true;
-                it++;
-                done = sqrt(step[0] * step[0] + step[1] * step[1] + step[2] * step[2]) < prm.tol_update;
-            } else {
-                lam *= 3;
-                adopt = false;
-                it++;
-                if (tx == cx && ty == cy && tr == rad) {
-                    it = prm.max_iter;           // every later candidate is this one again
-                    done = true;
-                }
-            }
-        }
-        if (adopt) {
-            cur = into;
-            hg = trial;
-            min_ri = trial[12];
-        }
-        if (done)
-            break;
-        // next candidate from the current H, g (a singular damped system costs an iteration, as in the reference)
-        bool have = false;
-        while (it < prm.max_iter) {
-            const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
-            double A[3][3] = {{hg[0] + lam * hg[0], hg[1], hg[2]},
-                              {hg[1], hg[3] + lam * hg[3], hg[4]},
-                              {hg[2], hg[4], hg[5] + lam * hg[5]}};
-            double b[3] = {g0, g1, g2};
-            if (!solve3x3(A, b, step)) {
-                lam *= 3;
-                it++;
-                continue;
-            }
-            step[0] = -step[0];
-            step[1] = -step[1];
-            step[2] = -step[2];
-            if (prev < inf) {
-                const double gd = fabs(g0 * step[0] + g1 * step[1] + g2 * step[2]);
-                const double dc2 = step[0] * step[0] + step[1] * step[1];
-                if (gd + hg[9] * dc2 < 0.25 * prm.tol_cost && 4.0 * dc2 <= min_ri * min_ri) {
-                    it = prm.max_iter;           // nothing from here on can be accepted
-                    break;
-                }
-            }
-            tx = cx + step[0];
-            ty = cy + step[1];
-            tr = rad + step[2];
-            if (!(tr > 1e-12))
-                tr = 1e-12;
-            have = true;
-            break;
-        }
-        if (!have)
-            break;
+    LmState st;
+    lm_begin(st, par, prm);
+    while (!st.done) {
+        const int into = lm_into(st);
+        sweep(st.tx, st.ty, st.tr, red.totals(into));
+        lm_step(st, prm, red.totals(0), into);
     }
-    par[0] = cx;
-    par[1] = cy;
-    par[2] = rad;
-    iters[0] = it;          // iterations the literal loop runs
-    iters[1] = acc_steps;   // accepted steps
-    iters[2] = n_first;     // sweeps that only built H and g (the first)
-    iters[3] = n_sweeps;    // sweeps that evaluated a candidate (cost, and H and g for the next step)
+    lm_finish(st, par, iters);
     ph.mark(4);
 }
 

@@ -484,6 +484,49 @@ def test_fit_on_ragged_slices_of_up_to_8192_points():
         assert np.array_equal(a[key], again[key], equal_nan=True), key          # bitwise reproducible
 
 
+def test_long_slices_on_the_segment_parallel_kernels():
+    """Batches with a slice of more than 8192 points are cut into segments, one workgroup each, and combined
+    per slice in a fixed order: a mix of lengths around the segment size, empty and tiny slices, outliers."""
+    lens = np.array([20000, 0, 8193, 2, 3, 100, 8192, 16384, 100001, 16385, 1, 50000])
+    S = len(lens)
+    x, y, _ = R.make_slices(1, int(lens.sum()), seed=12, outlier_frac=0.1, jitter=0.05)
+    off = np.zeros(S + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    k, st = F.kasa_batch(x, y, off)
+    init = np.where(np.isfinite(k), k, 1.0)
+    fit, it = F.lm_batch(x, y, off, init)
+    fitc = np.tile([3.01, -1.98, 10.02], (S, 1))
+    res = F.residuals_batch(x, y, off, fitc, bins=256, lo=-0.5, hi=0.5, want_radius=True)
+    sel = F.angle_max_batch(x, y, off, fitc, bins=720)
+    for s in range(S):
+        sl = slice(off[s], off[s + 1])
+        xy = np.stack([x[sl], y[sl]], 1)
+        so, ko = N.kasa(x[sl], y[sl])
+        assert so == st[s], s
+        if so == 0:
+            assert rel(k[s], ko) < 1e-11, s
+            lo_, _, _ = N.lm(x[sl], y[sl], init[s])
+            assert rel(fit[s], lo_) < 1e-7, s                      # (outliers: see LM_TOL)
+            assert it[s, 0] == 100 or lens[s] <= 3                # (an exact fit stops on a tiny step)
+        o = N.residuals(xy, *fitc[s], bins=256, lo=-0.5, hi=0.5)
+        assert np.array_equal(o["dr"], res["dr"][sl])
+        assert np.array_equal(o["hist"], res["hist"][s]), s
+        assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s]), s
+        if len(xy):
+            assert (o["rmax"], o["rmin"]) == (res["rmax"][s], res["rmin"][s])
+            assert np.max(np.abs(o["theta"] - res["theta"][sl])) <= THETA_ABS
+            assert np.array_equal(res["radius"][sl], N.polar(xy, fitc[s][0], fitc[s][1])[1])
+        assert np.array_equal(N.angle_max(xy, fitc[s][0], fitc[s][1], 720), sel[s]), s
+    k2, st2 = F.kasa_batch(x, y, off)
+    fit2, it2 = F.lm_batch(x, y, off, init)
+    assert np.array_equal(k, k2, equal_nan=True) and np.array_equal(fit, fit2, equal_nan=True)   # reproducible
+    # the same slices one by one: the short ones then run on the one-workgroup kernels
+    for s in (2, 5, 6):
+        sl = slice(off[s], off[s + 1])
+        k1, _ = F.kasa_batch(x[sl], y[sl], None)
+        assert rel(k1[0], k[s]) < 1e-12
+
+
 def test_full_size_ransac_30pct_outliers():
     """10 000 slices x 8192 points, 30 % outliers, 1024 hypotheses: bit-exact consensus on 24 replayed slices."""
     S, n = 10_000, 8192

@@ -37,7 +37,7 @@ if "c3" in which:
     del x, y, mask
 
 if "c4" in which:
-    N, S = int(os.environ.get("C4N", 100_000_000)), 2000
+    N, S = int(os.environ.get("C4N", 100_000_000)), int(os.environ.get("C4S", 2000))
     pts = make_cylinder(N, S, seed=3, outlier_frac=0.1)
     xyz = t(pts); del pts
     zc = np.arange(1.0, 2.0 * S - 1.0 + 1e-9, 2.0); lo, hi = zc - 1.0, zc + 1.0
@@ -45,7 +45,7 @@ if "c4" in which:
     geom = np.array([lo[0], hi[0], lo[-1]]); 
     wsb = L.pcfit_bin_workspace_bytes(N, S); ws = E(wsb // 8 + 1, dt=torch.int64)
     off = E(S + 1, dt=torch.int64)
-    timeit("C4 bin count (100M pts, 2000 windows)", lambda: F.check(L.pcfit_bin_count_dev(p(xyz), N, p(dlo), p(dhi), S, geom.ctypes.data, p(off), p(ws), wsb, st)), units=(N * 24 / 1e3, "GB/s"))
+    timeit(f"C4 bin count ({N//1000000}M pts, {S} windows)", lambda: F.check(L.pcfit_bin_count_dev(p(xyz), N, p(dlo), p(dhi), S, geom.ctypes.data, p(off), p(ws), wsb, st)), units=(N * 24 / 1e3, "GB/s"))
     tot = int(off[-1].item()); xo, yo = E(tot), E(tot)
     timeit("C4 bin scatter", lambda: F.check(L.pcfit_bin_scatter_dev(p(xyz), N, p(dlo), p(dhi), S, geom.ctypes.data, p(off), p(xo), p(yo), None, p(ws), wsb, st)), units=(N * 40 / 1e3, "GB/s"))
     maxlen = int((off[1:] - off[:-1]).max().item())
