@@ -49,7 +49,7 @@ static SplitPlan split_plan(int64_t total, int64_t S, int64_t bins)
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     p.max_segs = total / SPLIT_SEG + S + 1;
     p.segstart_off = 0;
-    p.part_off = up((size_t)(S + 1) * 8);
+    p.part_off = up((size_t)(S + 2) * 8);          // segstart[S + 1], then the count of slices still iterating
     p.slice_off = p.part_off + up((size_t)p.max_segs * SPLIT_PART * 8);
     p.bins_off = p.slice_off + up((size_t)std::max<int64_t>(S, 1) * sizeof(SplitSlice));
     p.bytes = p.bins_off + up((size_t)std::max<int64_t>(S, 1) * (size_t)std::max<int64_t>(bins, 0) * 8);
@@ -167,6 +167,10 @@ __global__ __launch_bounds__(SPLIT_BLOCK) void split_part_kernel(const double *_
 {
     __shared__ double scratch[13 * 16];
     __shared__ double tot[16];
+    if constexpr (MODE == 2) {
+        if (segstart[S + 1] == 0)       // every slice has finished: the rest of the enqueued rounds is idle
+            return;
+    }
     SegRef r;
     if (!find_segment(segstart, offsets, S, x, y, r))
         return;
@@ -278,7 +282,8 @@ __global__ __launch_bounds__(WAVE) void split_kasa_kernel(const int64_t *__restr
 // with init as the result, like the one-workgroup kernel after an unavailable Kasa fit)
 __global__ void split_lm_init_kernel(const int64_t *__restrict__ offsets, int64_t S, const double *__restrict__ init,
                                      LmParams prm, SplitSlice *__restrict__ slices, double *__restrict__ out,
-                                     int32_t *__restrict__ iters, const int32_t *__restrict__ skip_status)
+                                     int32_t *__restrict__ iters, const int32_t *__restrict__ skip_status,
+                                     int64_t *__restrict__ active)
 {
     const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (s >= S)
@@ -291,6 +296,8 @@ __global__ void split_lm_init_kernel(const int64_t *__restrict__ offsets, int64_
         st.done = true;
     slices[s].st = st;
     slices[s].finished = 0;
+    if (!st.done)
+        atomicAdd(reinterpret_cast<unsigned long long *>(active), 1ull);
     if (st.done) {
         out[3 * s] = par[0];
         out[3 * s + 1] = par[1];
@@ -305,9 +312,11 @@ __global__ void split_lm_init_kernel(const int64_t *__restrict__ offsets, int64_
 __global__ __launch_bounds__(WAVE) void split_lm_step_kernel(const int64_t *__restrict__ segstart,
                                                             const double *__restrict__ part, LmParams prm,
                                                             SplitSlice *__restrict__ slices, double *__restrict__ out,
-                                                            int32_t *__restrict__ iters)
+                                                            int32_t *__restrict__ iters, int64_t *__restrict__ active)
 {
     const int64_t s = blockIdx.x;
+    if (*active == 0)
+        return;
     SplitSlice &sl = slices[s];
     if (sl.finished)
         return;
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(WAVE) void split_lm_step_kernel(const int64_t *__re
                 for (int k = 0; k < 4; k++)
                     iters[4 * s + k] = it[k];
             sl.finished = 1;
+            atomicAdd(reinterpret_cast<unsigned long long *>(active), ~0ull);      // one slice fewer
         }
     }
 }
@@ -606,12 +616,15 @@ int split_lm(const double *x, const double *y, const int64_t *offsets, int64_t S
 {
     const dim3 grid((unsigned)w.plan.max_segs);
     split_map_kernel<<<dim3(1), dim3(1024), 0, st>>>(offsets, S, w.segstart);
+    int64_t *active = w.segstart + S + 1;
+    PCFIT_HIP(hipMemsetAsync(active, 0, 8, st));
     split_lm_init_kernel<<<dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st>>>(offsets, S, init, prm, w.slices, out,
-                                                                                   iters, skip_status);
+                                                                                   iters, skip_status, active);
     // one first sweep and at most max_iter candidate sweeps; finished slices cost a few loads per workgroup
     for (int32_t round = 0; round <= prm.max_iter; round++) {
         split_part_kernel<2><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, S, w.segstart, w.slices, prm, w.part);
-        split_lm_step_kernel<<<dim3((unsigned)S), dim3(WAVE), 0, st>>>(w.segstart, w.part, prm, w.slices, out, iters);
+        split_lm_step_kernel<<<dim3((unsigned)S), dim3(WAVE), 0, st>>>(w.segstart, w.part, prm, w.slices, out, iters,
+                                                                       active);
     }
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;

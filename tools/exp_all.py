@@ -57,6 +57,12 @@ if "c4" in which:
     timeit("C4 angle_max 720 bins", lambda: F.check(L.pcfit_angle_max_batch_dev(p(xo), p(yo), p(off), S, p(fit), 720, p(sel), st)), units=(tot * 16 / 1e3, "GB/s"))
     H = 256; edges = t(np.linspace(-0.5, 0.5, H + 1)); hist, rmm, amm = E(S, H, dt=torch.int64), E(S, 2), E(S, 2, dt=torch.int64)
     timeit("C4 residual hist", lambda: F.check(L.pcfit_residuals_batch_dev(p(xo), p(yo), p(off), S, p(fit), None, None, None, H, p(edges), p(hist), p(rmm), p(amm), st)), units=(tot * 16 / 1e3, "GB/s"))
+    swb = L.pcfit_split_workspace_bytes(tot, S, 720); sws = E(swb // 8 + 1, dt=torch.int64)
+    timeit("C4 split kasa", lambda: F.check(L.pcfit_kasa_split_dev(p(xo), p(yo), p(off), S, tot, p(kasa), p(status), p(sws), swb, st)), units=(tot * 32 / 1e3, "GB/s"))
+    timeit("C4 split kasa+lm", lambda: F.check(L.pcfit_fit_split_dev(p(xo), p(yo), p(off), S, tot, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), p(sws), swb, st)), units=(tot / 1e3, "M pts/s"))
+    print("   sweeps", iters[:3].tolist())
+    timeit("C4 split angle_max 720 bins", lambda: F.check(L.pcfit_angle_max_split_dev(p(xo), p(yo), p(off), S, tot, p(fit), 720, p(sel), p(sws), swb, st)), units=(tot * 32 / 1e3, "GB/s"))
+    timeit("C4 split residual hist", lambda: F.check(L.pcfit_residuals_split_dev(p(xo), p(yo), p(off), S, tot, p(fit), None, None, None, H, p(edges), p(hist), p(rmm), p(amm), p(sws), swb, st)), units=(tot * 16 / 1e3, "GB/s"))
     del xyz, xo, yo
 
 if "c1" in which:
