@@ -19,10 +19,22 @@
 //
 // A slice of up to 8192 points is sorted and hulled inside the 160 KB LDS
 // (16 B of coordinates + 2 B of index per point); longer slices run the same
-// code on a global-memory workspace.
+// code on a global-memory workspace - after a filter that drops the points
+// which cannot be hull vertices: around the slice's centroid c the plane is cut
+// into K sectors (128..512 by slice length), m = the smallest of the per-sector
+// largest distances from c, and every point closer to c than m cos(8/K) lies
+// strictly inside the convex hull of the sector maxima (two neighbours among
+// them are at most 16/K rad apart as seen from c, so the chord between them
+// stays outside that disc).
+// For a noisy ring that leaves a few percent of the points.  The filter runs
+// one workgroup per 8192 points; what it keeps is then sorted, made unique and
+// hulled as before, so hull vertices and their order are unchanged, while
+// n_unique / ux / uy of such a slice describe the kept points only and a
+// requested start vertex (an index into the full unique set) is not honoured.
 #include <algorithm>
 
 #include "pcfit_internal.h"
+#include "segments.h"
 
 namespace pcfit {
 
@@ -160,20 +172,180 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
     }
 }
 
+// ---- the filter for long slices
+constexpr int HULL_SECTORS = 512;
+constexpr int64_t HULL_FILTER_MAX_SLICES = 4096;       // (the per-slice sector table is 4 KB)
+
+struct HullSliceAux {
+    double cx, cy, thr;                 // centroid; squared distance below which a point is dropped
+    long long filtered;                 // 1: the slice went through the filter, kept points are in the workspace
+    unsigned long long kept;            // how many
+    long long sectors;                  // sectors in use: fewer for shorter slices, so that each still holds a crowd
+    unsigned long long sect[HULL_SECTORS];      // bit pattern + 1 of the largest squared distance per sector
+};
+
+// sector of a direction: uniform in the "diamond angle" dy / (|dx| + |dy|), whose slope against the
+// true angle lies in [1/2, 1], so one of K sectors is at most 8 / K radians wide
+__device__ __forceinline__ int sector_of(double dx, double dy, int K)
+{
+    const double a = fabs(dx) + fabs(dy);
+    if (!(a > 0.0))
+        return 0;
+    const double p = dy / a;
+    const double d = dx >= 0.0 ? (dy >= 0.0 ? p : 4.0 + p) : 2.0 - p;      // [0, 4)
+    const int j = (int)(d * (double)(K / 4));
+    return j < 0 ? 0 : (j > K - 1 ? K - 1 : j);
+}
+
+// PASS 0: partial coordinate sums.  PASS 1: per-sector largest squared distance.  PASS 2: copy the points
+// that are not provably inside to the workspace.  Slices that fit the LDS path are left alone.
+template <int PASS>
+__global__ __launch_bounds__(SPLIT_BLOCK) void hull_filter_kernel(const double *__restrict__ x,
+                                                                 const double *__restrict__ y,
+                                                                 const int64_t *__restrict__ offsets, int64_t S,
+                                                                 const int64_t *__restrict__ segstart, int lds_cap,
+                                                                 HullSliceAux *__restrict__ aux,
+                                                                 double *__restrict__ part, double *__restrict__ wsx,
+                                                                 double *__restrict__ wsy)
+{
+    __shared__ double red[2 * 16];
+    __shared__ unsigned long long lsect[HULL_SECTORS];
+    SegRef r;
+    if (!find_segment(segstart, offsets, S, x, y, r))
+        return;
+    const int64_t off = offsets[r.slice];
+    if (offsets[r.slice + 1] - off <= lds_cap)
+        return;
+    if constexpr (PASS == 0) {
+        double s1[2] = {0.0, 0.0};
+        segment_points(r, [&](double px, double py, int32_t, bool valid) {
+            s1[0] += valid ? px : 0.0;
+            s1[1] += valid ? py : 0.0;
+        });
+        block_sum<2>(s1, red);
+        if (threadIdx.x == 0) {
+            part[r.seg * SPLIT_PART] = s1[0];
+            part[r.seg * SPLIT_PART + 1] = s1[1];
+        }
+    } else if constexpr (PASS == 1) {
+        for (int j = threadIdx.x; j < HULL_SECTORS; j += SPLIT_BLOCK)
+            lsect[j] = 0ull;
+        __syncthreads();
+        const double cx = aux[r.slice].cx, cy = aux[r.slice].cy;
+        const int K = (int)aux[r.slice].sectors;
+        segment_points(r, [&](double px, double py, int32_t, bool valid) {
+            const double dx = px - cx, dy = py - cy;
+            const double r2 = dx * dx + dy * dy;
+            if (valid && r2 < __longlong_as_double(0x7ff0000000000000ll))
+                atomicMax(&lsect[sector_of(dx, dy, K)], (unsigned long long)__double_as_longlong(r2) + 1ull);
+        });
+        __syncthreads();
+        for (int j = threadIdx.x; j < HULL_SECTORS; j += SPLIT_BLOCK)
+            if (lsect[j])
+                atomicMax(&aux[r.slice].sect[j], lsect[j]);
+    } else {
+        const double cx = aux[r.slice].cx, cy = aux[r.slice].cy, thr = aux[r.slice].thr;
+        const int lane = threadIdx.x & 63;
+        segment_points(r, [&](double px, double py, int32_t, bool valid) {
+            const double dx = px - cx, dy = py - cy;
+            const double r2 = dx * dx + dy * dy;
+            const bool keep = valid && !(r2 < thr);            // (a NaN stays)
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                unsigned long long base = 0;
+                const int leader = __ffsll((long long)m) - 1;
+                if (lane == leader)
+                    base = atomicAdd(&aux[r.slice].kept, (unsigned long long)__popcll(m));
+                base = __shfl(base, leader, WAVE);
+                if (keep) {
+                    const unsigned long long at = base + __popcll(m & ((1ull << lane) - 1ull));
+                    wsx[off + at] = px;
+                    wsy[off + at] = py;
+                }
+            }
+        });
+    }
+}
+
+// per slice, between the passes: STEP 0 centroid from the partial sums and a clean table,
+// STEP 1 the threshold from the table
+template <int STEP>
+__global__ __launch_bounds__(WAVE) void hull_filter_slice_kernel(const int64_t *__restrict__ offsets,
+                                                                const int64_t *__restrict__ segstart, int lds_cap,
+                                                                const double *__restrict__ part,
+                                                                HullSliceAux *__restrict__ aux)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t n = offsets[s + 1] - offsets[s];
+    HullSliceAux &a = aux[s];
+    if (n <= lds_cap) {
+        if (threadIdx.x == 0 && STEP == 0)
+            a.filtered = 0;
+        return;
+    }
+    if constexpr (STEP == 0) {
+        double v[2] = {0.0, 0.0};
+        const int64_t seg0 = segstart[s], nseg = segstart[s + 1] - seg0;
+        for (int64_t j = threadIdx.x; j < nseg; j += WAVE) {
+            v[0] += part[(seg0 + j) * SPLIT_PART];
+            v[1] += part[(seg0 + j) * SPLIT_PART + 1];
+        }
+        v[0] = wave_sum(v[0]);
+        v[1] = wave_sum(v[1]);
+        for (int j = threadIdx.x; j < HULL_SECTORS; j += WAVE)
+            a.sect[j] = 0ull;
+        if (threadIdx.x == 0) {
+            a.cx = v[0] / (double)n;
+            a.cy = v[1] / (double)n;
+            a.filtered = 1;
+            a.kept = 0ull;
+            a.sectors = n >= 200000 ? HULL_SECTORS : (n >= 60000 ? HULL_SECTORS / 2 : HULL_SECTORS / 4);
+        }
+    } else {
+        const int K = (int)a.sectors;
+        unsigned long long m = ~0ull;
+        for (int j = threadIdx.x; j < K; j += WAVE)
+            m = a.sect[j] < m ? a.sect[j] : m;
+#pragma unroll
+        for (int k = 32; k >= 1; k >>= 1) {
+            const unsigned long long o = __shfl_xor(m, k, WAVE);
+            m = o < m ? o : m;
+        }
+        if (threadIdx.x == 0) {
+            // an empty sector (or a centroid that is not finite): nothing can be dropped
+            double thr = 0.0;
+            if (m != 0ull && a.cx == a.cx && a.cy == a.cy) {
+                const double m2 = __longlong_as_double((long long)(m - 1ull));
+                const double c = cos(8.0 / (double)K);
+                thr = m2 * (c * c) * (1.0 - 1e-9);
+            }
+            a.thr = thr;
+        }
+    }
+}
+
 template <bool IN_LDS, class IdxT>
 __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, int lds_cap,
     double *__restrict__ ux, double *__restrict__ uy, int64_t *__restrict__ n_unique, int64_t *__restrict__ hull_idx,
     int64_t *__restrict__ n_hull, int32_t *__restrict__ status, const int64_t *__restrict__ hull_start,
     double *__restrict__ wsx, double *__restrict__ wsy, uint32_t *__restrict__ wslist,
-    uint32_t *__restrict__ wspark)
+    uint32_t *__restrict__ wspark, const HullSliceAux *__restrict__ aux)
 {
     extern __shared__ double lds_dyn[];
     __shared__ double red[9 * 16];
     __shared__ int scan_scratch[17];
     __shared__ int found_at;
     const int64_t s = blockIdx.x;
-    const int64_t off = offsets[s], n = offsets[s + 1] - off;
+    const int64_t off = offsets[s];
+    int64_t n = offsets[s + 1] - off;
+    const double *src_x = x + off, *src_y = y + off;
+    const bool filtered = aux && aux[s].filtered == 1;
+    if (filtered) {
+        n = (int64_t)aux[s].kept;                        // what the filter kept waits in the workspace
+        src_x = wsx + off;
+        src_y = wsy + off;
+    }
     if (IN_LDS ? (n > lds_cap) : (n <= lds_cap))
         return;                                          // the other launch takes this slice
     double *px, *py;
@@ -194,9 +366,11 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         n_hull[s] = 0;
         status[s] = PCFIT_ST_OK;
     }
-    for (int64_t i = tid; i < n; i += HULL_BLOCK) {
-        px[i] = x[off + i];
-        py[i] = y[off + i];
+    if (IN_LDS || !filtered) {                           // (filtered and in global memory: already in place)
+        for (int64_t i = tid; i < n; i += HULL_BLOCK) {
+            px[i] = src_x[i];
+            py[i] = src_y[i];
+        }
     }
     __syncthreads();
 
@@ -327,7 +501,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
     __syncthreads();
     // optional rotation of the walk to a requested first vertex
-    const int64_t want = hull_start ? hull_start[s] : -1;
+    const int64_t want = hull_start && !filtered ? hull_start[s] : -1;
     if (want > 0) {
         for (int64_t i = tid; i < h; i += HULL_BLOCK) {
             const int64_t v = pong[i];
@@ -344,15 +518,35 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
 }
 
+// Workspace: wsx, wsy (8 B per point each), wslist, wspark (4 B each), then - for batches of at most
+// HULL_FILTER_MAX_SLICES slices - the filter's segment table, partial sums and per-slice records.
+struct HullLayout {
+    size_t total, seg_off, part_off, aux_off, bytes;
+    int64_t max_segs;
+    bool filter;
+};
+
+static HullLayout hull_layout(size_t total, int64_t S)
+{
+    HullLayout l;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    l.total = total;
+    l.filter = S <= HULL_FILTER_MAX_SLICES;
+    l.max_segs = (int64_t)(total / SPLIT_SEG) + S + 1;
+    l.seg_off = up(total * 24 + 1024);
+    l.part_off = l.seg_off + (l.filter ? up((size_t)(S + 2) * 8) : 0);
+    l.aux_off = l.part_off + (l.filter ? up((size_t)l.max_segs * SPLIT_PART * 8) : 0);
+    l.bytes = l.aux_off + (l.filter ? up((size_t)std::max<int64_t>(S, 1) * sizeof(HullSliceAux)) : 0);
+    return l;
+}
+
 }  // namespace pcfit
 
 using namespace pcfit;
 
 PCFIT_API size_t pcfit_unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices)
 {
-    (void)n_slices;
-    const size_t t = (size_t)(total_points > 0 ? total_points : 1);
-    return t * 8 * 2 + t * 4 * 2 + 1024;               // wsx, wsy, wslist, wspark
+    return hull_layout((size_t)(total_points > 0 ? total_points : 1), std::max<int64_t>(n_slices, 0)).bytes;
 }
 
 PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
@@ -368,13 +562,22 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
                   "unique_hull: null pointer");
     PCFIT_REQUIRE(max_slice_len >= 0 && max_slice_len < (1ll << 31),
                   "unique_hull: max_slice_len must be given (0..2^31-1)");
-    // total points are not known here (offsets live on the device): the caller sized the workspace
-    // with pcfit_unique_hull_workspace_bytes(total); the layout below needs total = (bytes-1024)/24
-    if (!workspace || workspace_bytes < 1024 + 24) {
+    // total points are not known here (offsets live on the device): the caller sized the workspace with
+    // pcfit_unique_hull_workspace_bytes(total, n_slices); the largest total whose layout fits is the one
+    if (!workspace || workspace_bytes < hull_layout(1, n_slices).bytes) {
         set_error("unique_hull: workspace missing");
         return PCFIT_ERR_WORKSPACE;
     }
-    const size_t total = (workspace_bytes - 1024) / 24;
+    size_t lo = 1, hi = workspace_bytes / 24;
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo + 1) / 2;
+        if (hull_layout(mid, n_slices).bytes <= workspace_bytes)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const HullLayout l = hull_layout(lo, n_slices);
+    const size_t total = l.total;
     char *ws = static_cast<char *>(workspace);
     double *wsx = reinterpret_cast<double *>(ws);
     double *wsy = wsx + total;
@@ -383,15 +586,32 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
     hipStream_t st = as_stream(stream);
     int cap = (int)std::min<int64_t>(HULL_LDS_CAP, std::max<int64_t>(64, (max_slice_len + 63) / 64 * 64));
     const size_t lds = (size_t)cap * 18;
+    HullSliceAux *aux = nullptr;
+    if (l.filter && max_slice_len > cap) {
+        int64_t *segstart = reinterpret_cast<int64_t *>(ws + l.seg_off);
+        double *part = reinterpret_cast<double *>(ws + l.part_off);
+        aux = reinterpret_cast<HullSliceAux *>(ws + l.aux_off);
+        const dim3 grid((unsigned)l.max_segs), per_slice((unsigned)n_slices);
+        split_map_kernel<<<dim3(1), dim3(1024), 0, st>>>(offsets, n_slices, segstart);
+        hull_filter_kernel<0><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, n_slices, segstart, cap, aux, part, wsx,
+                                                                  wsy);
+        hull_filter_slice_kernel<0><<<per_slice, dim3(WAVE), 0, st>>>(offsets, segstart, cap, part, aux);
+        hull_filter_kernel<1><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, n_slices, segstart, cap, aux, part, wsx,
+                                                                  wsy);
+        hull_filter_slice_kernel<1><<<per_slice, dim3(WAVE), 0, st>>>(offsets, segstart, cap, part, aux);
+        hull_filter_kernel<2><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, n_slices, segstart, cap, aux, part, wsx,
+                                                                  wsy);
+        PCFIT_LAUNCH_CHECK();
+    }
     // more than 64 KB of dynamic LDS has to be granted explicitly (per device; idempotent)
     PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&unique_hull_kernel<true, uint16_t>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, HULL_LDS_CAP * 18));
     unique_hull_kernel<true, uint16_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), lds, st>>>(
-        x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark);
+        x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux);
     PCFIT_LAUNCH_CHECK();
     if (max_slice_len > cap) {
         unique_hull_kernel<false, uint32_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), 0, st>>>(
-            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark);
+            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux);
         PCFIT_LAUNCH_CHECK();
     }
     return PCFIT_OK;
