@@ -260,7 +260,8 @@ int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, u
  *     to start from - lets a caller replay Qhull's order).
  * Out (capacity of every per-point array = offsets[S]):
  *     status S (0 ok / 1 / 2 / 3: the reference returns None), fit S*3,
- *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy),
+ *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy); ux and uy may be NULL
+ *                                when the caller does not want them copied back,
  *     cand_offsets S+1, cand_x, cand_y, mask     candidates_xy and inlier_mask,
  *     radius, theta              hypot and angle of every candidate about the fit,
  *     argmax_argmin S*2          candidate indices of the largest / smallest radius,
@@ -272,6 +273,26 @@ int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets,
                        int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
                        double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
                        int64_t grid_len);
+
+/* A whole scan in one call: CylinderAnalyzer.analyze_with_progress /
+ * analyze_file (analyzer.py:131-243) cut the scan into the windows
+ * [z_lo[s], z_hi[s]] (analyzer.py:49-52) and run process_slice on each; here
+ * xyz (n_points*3, row-major) goes to the device once, is binned there
+ * (pcfit_bin_slices' rules: uniform windows, file order kept inside a window)
+ * and the hybrid chain above runs on the device-resident slices.  Only
+ * per-slice results and the candidates come back:
+ *     offsets n_slices+1         CSR offsets of the windows (n_points_slice = their differences),
+ *     the outputs of pcfit_hybrid_batch without ux / uy; the candidate arrays
+ *     (cand_x, cand_y, mask, radius, theta) hold cand_capacity entries and the
+ *     call fails with PCFIT_ERR_INVALID, naming the count, when more are needed.
+ * hull_start is not offered: every hull is walked from its lexicographic minimum. */
+int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                            int64_t n_slices, double inlier_tol, int32_t max_trials, double min_inliers_frac,
+                            const double *r_range, double huber_delta, int32_t use_hull, uint64_t seed,
+                            int64_t *offsets, int32_t *status, double *fit, int64_t *n_unique,
+                            int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
+                            double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
+                            int64_t grid_len, int64_t cand_capacity);
 
 #ifdef __cplusplus
 }

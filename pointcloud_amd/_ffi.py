@@ -83,6 +83,8 @@ SIGNATURES = {
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
                            + [_i64]),
+    "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
+                                + [_vp] * 13 + [_i64, _i64]),
 }
 
 
@@ -269,15 +271,18 @@ def circle3_batch(triples):
     return out, ok.astype(bool)
 
 
+OV_CAP = 8192          # most candidates per slice the ovality kernel takes (pipeline.hip)
+
+
 def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
-                 huber_delta=1.0, use_hull=True, hull_start=None, seed=42, want_profile=True):
+                 huber_delta=1.0, use_hull=True, hull_start=None, seed=42, want_profile=True, want_unique=True):
     """fit_circle_hybrid_at_z + the metrics of process_slice for every slice of a CSR batch."""
     x, y, offsets = as_csr(x, y, offsets)
     S = offsets.size - 1
     tot = max(int(x.size), 1)
     status = np.zeros(S, np.int32)
     fit = np.full((S, 3), np.nan)
-    ux, uy = np.zeros(tot), np.zeros(tot)
+    ux, uy = (np.zeros(tot), np.zeros(tot)) if want_unique else (None, None)
     n_unique = np.zeros(S, np.int64)
     cand_off = np.zeros(S + 1, np.int64)
     cx_, cy_ = np.zeros(tot), np.zeros(tot)
@@ -285,7 +290,7 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
     radius, theta = np.zeros(tot), np.zeros(tot)
     amm = np.zeros((S, 2), np.int64)
     ov = np.zeros((S, 5))
-    K = int(max(1024, np.diff(offsets).max() if S else 0))
+    K = int(max(1024, min(OV_CAP, np.diff(offsets).max() if S else 0)))
     dev = np.full((S, K), np.nan) if want_profile else None
     rr = None if r_range is None else _arr(r_range, np.float64)
     hs = None if hull_start is None else _arr(hull_start, np.int64)
@@ -295,5 +300,49 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
                                    _p(theta), _p(amm), _p(ov), _p(dev), K))
     nc = int(cand_off[-1])
     return dict(status=status, fit=fit, ux=ux, uy=uy, n_unique=n_unique, offsets=offsets, cand_offsets=cand_off,
+                cand_x=cx_[:nc], cand_y=cy_[:nc], mask=mask[:nc].astype(bool), radius=radius[:nc], theta=theta[:nc],
+                argmax=amm[:, 0], argmin=amm[:, 1], ov=ov, dev_uniform=dev, grid_len=K)
+
+
+def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
+                      huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None):
+    """bin_slices + hybrid_batch without the round trip of the binned points: the scan is uploaded once and
+    only per-slice results and candidates come back.  With hull candidates the candidate arrays start small
+    and the call is repeated once with the needed size if they were too small."""
+    pts = _arr(points, np.float64)
+    if pts.ndim != 2 or pts.shape[1] != 3:
+        raise ValueError("points must be (N,3)")
+    z_lo = _arr(z_lo, np.float64)
+    z_hi = _arr(z_hi, np.float64)
+    S = z_lo.size
+    N = pts.shape[0]
+    if cand_capacity is None:
+        cand_capacity = 2 * N if not use_hull else min(2 * N, max(1 << 20, 1024 * S))
+    rr = None if r_range is None else _arr(r_range, np.float64)
+    K = OV_CAP
+    while True:
+        cap = max(int(cand_capacity), 1)
+        offsets = np.zeros(S + 1, np.int64)
+        status = np.zeros(S, np.int32)
+        fit = np.full((S, 3), np.nan)
+        n_unique = np.zeros(S, np.int64)
+        cand_off = np.zeros(S + 1, np.int64)
+        cx_, cy_ = np.zeros(cap), np.zeros(cap)
+        mask = np.zeros(cap, np.uint8)
+        radius, theta = np.zeros(cap), np.zeros(cap)
+        amm = np.zeros((S, 2), np.int64)
+        ov = np.zeros((S, 5))
+        dev = np.full((S, K), np.nan) if want_profile else None
+        rc = lib().pcfit_scan_hybrid_batch(_p(pts), N, _p(z_lo), _p(z_hi), S, inlier_tol, max_trials,
+                                           min_inliers_frac, _p(rr), huber_delta, 1 if use_hull else 0, int(seed),
+                                           _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off), _p(cx_),
+                                           _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
+        if rc != 0 and int(cand_off[-1]) > cap:           # candidate arrays too small: the count is known now
+            cand_capacity = int(cand_off[-1])
+            continue
+        check(rc)
+        break
+    nc = int(cand_off[-1])
+    return dict(status=status, fit=fit, n_unique=n_unique, offsets=offsets, cand_offsets=cand_off,
                 cand_x=cx_[:nc], cand_y=cy_[:nc], mask=mask[:nc].astype(bool), radius=radius[:nc], theta=theta[:nc],
                 argmax=amm[:, 0], argmin=amm[:, 1], ov=ov, dev_uniform=dev, grid_len=K)

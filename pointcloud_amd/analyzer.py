@@ -56,7 +56,8 @@ class CylinderAnalyzer:
         z_centers = np.asarray(z_centers, float)
         offsets, x, y, _ = _ffi.bin_slices(points, z_centers - dz, z_centers + dz, want_perm=False)
         h = _ffi.hybrid_batch(x, y, offsets, _FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None,
-                              _FIT["huber_delta"], _FIT["use_hull"], hull_start, want_profile=want_profile)
+                              _FIT["huber_delta"], _FIT["use_hull"], hull_start, want_profile=want_profile,
+                              want_unique=False)
         return offsets, x, y, h
 
     def _slice_result(self, s: int, z_center, n0: int, h: dict):
@@ -154,8 +155,12 @@ class CylinderAnalyzer:
         """Yield (result, edge columns or None, warning) per window, in window order."""
         if len(z_centers) == 0:
             return
-        offsets, x, y, h = self._run_windows(points, z_centers, want_profile=False)
-        counts = np.diff(offsets)
+        dz = self.config.z_step / 2.0
+        z_centers = np.asarray(z_centers, float)
+        # the scan is uploaded once and binned on the device; only per-window results come back
+        h = _ffi.scan_hybrid_batch(points, z_centers - dz, z_centers + dz, _FIT["inlier_tol"], _FIT["max_trials"],
+                                   _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"])
+        counts = np.diff(h["offsets"])
         for s, zc in enumerate(z_centers):
             n0 = int(counts[s])
             if n0 < self.config.min_points_per_slice:

@@ -316,6 +316,22 @@ static int bin_geom(const double *z_lo_host3, int64_t S, BinGeom &g)
     return PCFIT_OK;
 }
 
+// the windows must be what analyzer.py:240-243 builds: ascending, near-uniform; geom = what the _dev calls take
+int bin_check_windows(const double *z_lo, const double *z_hi, int64_t n_slices, double geom[3])
+{
+    const double step = n_slices > 1 ? (z_lo[n_slices - 1] - z_lo[0]) / (double)(n_slices - 1) : 1.0;
+    const double width = z_hi[0] - z_lo[0];
+    for (int64_t s = 0; s < n_slices; s++) {
+        const double want = z_lo[0] + (double)s * step;
+        PCFIT_REQUIRE(fabs(z_lo[s] - want) <= 1e-7 * step && fabs((z_hi[s] - z_lo[s]) - width) <= 1e-7 * step,
+                      "bin: windows are not uniformly spaced (window %lld)", (long long)s);
+    }
+    geom[0] = z_lo[0];
+    geom[1] = z_hi[0];
+    geom[2] = z_lo[n_slices - 1];
+    return PCFIT_OK;
+}
+
 }  // namespace pcfit
 
 using namespace pcfit;
@@ -399,15 +415,8 @@ PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double
 {
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     PCFIT_REQUIRE(z_lo && z_hi && offsets && total && (xyz || n_points == 0), "bin: null pointer");
-    // the windows must be what analyzer.py:240-243 builds: ascending, near-uniform
-    const double step = n_slices > 1 ? (z_lo[n_slices - 1] - z_lo[0]) / (double)(n_slices - 1) : 1.0;
-    const double width = z_hi[0] - z_lo[0];
-    for (int64_t s = 0; s < n_slices; s++) {
-        const double want = z_lo[0] + (double)s * step;
-        PCFIT_REQUIRE(fabs(z_lo[s] - want) <= 1e-7 * step && fabs((z_hi[s] - z_lo[s]) - width) <= 1e-7 * step,
-                      "bin: windows are not uniformly spaced (window %lld)", (long long)s);
-    }
-    const double geom[3] = {z_lo[0], z_hi[0], z_lo[n_slices - 1]};
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
     hipStream_t st = nullptr;
     void *d_xyz = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_off = nullptr, *d_ws = nullptr, *d_x = nullptr,
          *d_y = nullptr, *d_perm = nullptr;

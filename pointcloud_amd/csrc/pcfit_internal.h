@@ -14,6 +14,7 @@
 namespace pcfit {
 
 void set_error(const char *fmt, ...);
+int bin_check_windows(const double *z_lo, const double *z_hi, int64_t n_slices, double geom[3]);   // bin.hip
 
 #define PCFIT_HIP(call)                                                                       \
     do {                                                                                      \

@@ -362,29 +362,19 @@ PCFIT_API int pcfit_ovality_batch(const double *x, const double *y, const int64_
     return PCFIT_OK;
 }
 
-PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
-                                 double inlier_tol, int32_t max_trials, double min_inliers_frac,
-                                 const double *r_range, double huber_delta, int32_t use_hull,
-                                 const int64_t *hull_start, uint64_t seed, int32_t *status, double *fit, double *ux,
-                                 double *uy, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
-                                 double *cand_y, uint8_t *mask, double *radius, double *theta,
-                                 int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len)
+// The chain on slices that are already on the device (dxp, dyp, doffp; offsets = the same CSR offsets on
+// the host).  ux / uy may be null (then the distinct points stay on the device); the candidate arrays hold
+// cand_capacity entries.
+static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doffp, const int64_t *offsets, int64_t S,
+                       int64_t total, int64_t max_len, double inlier_tol, int32_t max_trials, double min_inliers_frac,
+                       const double *r_range, double huber_delta, int32_t use_hull, const int64_t *hull_start,
+                       uint64_t seed, int32_t *status, double *fit, double *ux, double *uy, int64_t *n_unique,
+                       int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
+                       double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
+                       int64_t cand_capacity, hipStream_t st)
 {
-    int64_t total, max_len;
-    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
-    if (n_slices == 0) return PCFIT_OK;
-    const int64_t S = n_slices;
-    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "hybrid: null pointer");
-    PCFIT_REQUIRE(total == 0 || (x && y && ux && uy && cand_x && cand_y && mask && radius && theta),
-                  "hybrid: null pointer");
-    PCFIT_REQUIRE(max_trials >= 0, "hybrid: max_trials negative");
-    hipStream_t st = nullptr;
-
     // 1. distinct points, rank check, hull
-    DevBuf dx, dy, doff, dux, duy, dnu, dhi, dnh, dst, dhs, dws;
-    PCFIT_TRY(dx.upload(x, total * 8, st));
-    PCFIT_TRY(dy.upload(y, total * 8, st));
-    PCFIT_TRY(doff.upload(offsets, (S + 1) * 8, st));
+    DevBuf dux, duy, dnu, dhi, dnh, dst, dhs, dws;
     PCFIT_TRY(dux.alloc(total * 8));
     PCFIT_TRY(duy.alloc(total * 8));
     PCFIT_TRY(dnu.alloc(S * 8));
@@ -393,7 +383,7 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
     PCFIT_TRY(dst.alloc(S * 4));
     if (hull_start) PCFIT_TRY(dhs.upload(hull_start, S * 8, st));
     PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, S)));
-    PCFIT_TRY(pcfit_unique_hull_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), S, max_len,
+    PCFIT_TRY(pcfit_unique_hull_batch_dev(dxp, dyp, doffp, S, max_len,
                                           dux.as<double>(), duy.as<double>(), dnu.as<int64_t>(), dhi.as<int64_t>(),
                                           dnh.as<int64_t>(), dst.as<int32_t>(), dhs.as<int64_t>(), dws.p, dws.bytes,
                                           st));
@@ -415,13 +405,18 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
         max_cand = std::max(max_cand, m);
     }
     const int64_t n_cand = cand_offsets[S];
+    if (n_cand > cand_capacity) {
+        set_error("hybrid: the candidate arrays hold %lld entries, %lld needed", (long long)cand_capacity,
+                  (long long)n_cand);
+        return PCFIT_ERR_INVALID;
+    }
     PCFIT_TRY(dst.upload(status, S * 4, st));
     DevBuf dco, dcx, dcy;
     PCFIT_TRY(dco.upload(cand_offsets, (S + 1) * 8, st));
     PCFIT_TRY(dcx.alloc(n_cand * 8));
     PCFIT_TRY(dcy.alloc(n_cand * 8));
     gather_candidates_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dux.as<double>(), duy.as<double>(),
-                                                                     doff.as<int64_t>(), dhi.as<int64_t>(),
+                                                                     doffp, dhi.as<int64_t>(),
                                                                      dco.as<int64_t>(), use_hull ? 1 : 0,
                                                                      dcx.as<double>(), dcy.as<double>(),
                                                                      dst.as<int32_t>());
@@ -500,8 +495,8 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
                                       dfit.as<double>(), dov.as<double>(), ddev.as<double>(), grid_len, st));
 
     PCFIT_TRY(dfit.download(fit, S * 24, st));
-    PCFIT_TRY(dux.download(ux, total * 8, st));
-    PCFIT_TRY(duy.download(uy, total * 8, st));
+    if (ux) PCFIT_TRY(dux.download(ux, total * 8, st));
+    if (uy) PCFIT_TRY(duy.download(uy, total * 8, st));
     PCFIT_TRY(dcx.download(cand_x, n_cand * 8, st));
     PCFIT_TRY(dcy.download(cand_y, n_cand * 8, st));
     PCFIT_TRY(dmask.download(mask, n_cand, st));
@@ -512,6 +507,74 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
     if (dev_uniform) PCFIT_TRY(ddev.download(dev_uniform, (size_t)S * grid_len * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                 double inlier_tol, int32_t max_trials, double min_inliers_frac,
+                                 const double *r_range, double huber_delta, int32_t use_hull,
+                                 const int64_t *hull_start, uint64_t seed, int32_t *status, double *fit, double *ux,
+                                 double *uy, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                                 double *cand_y, uint8_t *mask, double *radius, double *theta,
+                                 int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len)
+{
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    const int64_t S = n_slices;
+    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "hybrid: null pointer");
+    PCFIT_REQUIRE(total == 0 || (x && y && cand_x && cand_y && mask && radius && theta), "hybrid: null pointer");
+    PCFIT_REQUIRE(max_trials >= 0, "hybrid: max_trials negative");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (S + 1) * 8, st));
+    return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
+                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, hull_start, seed, status, fit, ux,
+                       uy, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal,
+                       dev_uniform, grid_len, total, st);
+}
+
+PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                      int64_t n_slices, double inlier_tol, int32_t max_trials,
+                                      double min_inliers_frac, const double *r_range, double huber_delta,
+                                      int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status, double *fit,
+                                      int64_t *n_unique, int64_t *cand_offsets, double *cand_x, double *cand_y,
+                                      uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin,
+                                      double *ov_scal, double *dev_uniform, int64_t grid_len, int64_t cand_capacity)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "scan_hybrid: need n_points >= 0 and n_slices >= 1");
+    PCFIT_REQUIRE(z_lo && z_hi && offsets && (xyz || n_points == 0), "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(cand_capacity >= 0 && (cand_capacity == 0 || (cand_x && cand_y && mask && radius && theta)),
+                  "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(max_trials >= 0, "scan_hybrid: max_trials negative");
+    const int64_t S = n_slices;
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
+    hipStream_t st = nullptr;
+    // the scan goes to the device once; slices are formed and stay there
+    DevBuf dxyz, dlo, dhi, doff, dbw, dx, dy;
+    PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
+    PCFIT_TRY(dlo.upload(z_lo, S * 8, st));
+    PCFIT_TRY(dhi.upload(z_hi, S * 8, st));
+    PCFIT_TRY(doff.alloc((S + 1) * 8));
+    const size_t bws = pcfit_bin_workspace_bytes(n_points, S);
+    PCFIT_TRY(dbw.alloc(bws));
+    PCFIT_TRY(pcfit_bin_count_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), S, geom,
+                                  doff.as<int64_t>(), dbw.p, bws, st));
+    PCFIT_TRY(doff.download(offsets, (S + 1) * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
+    PCFIT_TRY(dx.alloc((size_t)total * 8));
+    PCFIT_TRY(dy.alloc((size_t)total * 8));
+    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), S, geom,
+                                    doff.as<int64_t>(), dx.as<double>(), dy.as<double>(), nullptr, dbw.p, bws, st));
+    return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
+                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, seed, status, fit,
+                       nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,
+                       ov_scal, dev_uniform, grid_len, cand_capacity, st);
 }
 
 PCFIT_API int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,

@@ -630,3 +630,24 @@ def test_scan_sized_boundary_and_histogram_pass():
         o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
         assert np.array_equal(o["hist"], res["hist"][s])
         assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
+
+
+def test_scan_level_call_matches_bin_then_hybrid():
+    """pcfit_scan_hybrid_batch (scan uploaded once, binned and fitted on the device) returns what
+    pcfit_bin_slices followed by pcfit_hybrid_batch returns, bit for bit."""
+    from pointcloud_amd.synth import make_cylinder
+    pts = make_cylinder(300_000, 40, seed=11, outlier_frac=0.05)
+    zc = np.arange(pts[:, 2].min() + 1.0, pts[:, 2].max() - 1.0 + 1e-9, 2.0)
+    off, x, y, _ = F.bin_slices(pts, zc - 1.0, zc + 1.0, want_perm=False)
+    a = F.hybrid_batch(x, y, off, want_profile=True)
+    b = F.scan_hybrid_batch(pts, zc - 1.0, zc + 1.0, want_profile=True)
+    assert np.array_equal(off, b["offsets"])
+    for k in ("status", "n_unique", "cand_offsets", "cand_x", "cand_y", "mask", "radius", "theta", "argmax", "argmin"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["fit"], b["fit"], equal_nan=True)
+    assert np.array_equal(a["ov"], b["ov"], equal_nan=True)
+    K = min(a["grid_len"], b["grid_len"])
+    assert np.array_equal(a["dev_uniform"][:, :K], b["dev_uniform"][:, :K], equal_nan=True)
+    # candidate arrays that are too small are grown and the call repeated
+    c = F.scan_hybrid_batch(pts, zc - 1.0, zc + 1.0, cand_capacity=7)
+    assert np.array_equal(c["cand_x"], a["cand_x"]) and np.array_equal(c["fit"], a["fit"], equal_nan=True)
