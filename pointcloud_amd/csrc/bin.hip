@@ -31,6 +31,7 @@
 namespace pcfit {
 
 constexpr int BIN_SEG = 64;            // chunk rows per scan segment
+constexpr int BIN_UNROLL = 4;          // 64-point trips whose loads are issued together
 constexpr int64_t BIN_MAX_SLICES = 16384;
 constexpr double BIN_EDGE_EPS = 1e-6;  // in units of the window step
 
@@ -86,14 +87,24 @@ __global__ __launch_bounds__(64) void bin_count_kernel(const double *__restrict_
         lhist[s] = 0;
     __syncthreads();
     const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
-    for (int64_t i = begin + threadIdx.x; i < end; i += 64) {
-        int32_t k1;
-        bool has2;
-        windows_of(xyz[3 * i + 2], g, z_lo, z_hi, k1, has2);
-        if (k1 >= 0) {
-            atomicAdd(&lhist[k1], 1u);
-            if (has2)
-                atomicAdd(&lhist[k1 + 1], 1u);
+    // BIN_UNROLL loads of z in flight per lane: one wave per chunk has nothing else to hide the latency with
+    for (int64_t base = begin + threadIdx.x; base < end; base += 64 * BIN_UNROLL) {
+        double z[BIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BIN_UNROLL; u++) {
+            const int64_t i = base + 64 * u;
+            z[u] = i < end ? xyz[3 * i + 2] : __longlong_as_double(0x7ff8000000000000ll);   // NaN: no window
+        }
+#pragma unroll
+        for (int u = 0; u < BIN_UNROLL; u++) {
+            int32_t k1;
+            bool has2;
+            windows_of(z[u], g, z_lo, z_hi, k1, has2);
+            if (k1 >= 0) {
+                atomicAdd(&lhist[k1], 1u);
+                if (has2)
+                    atomicAdd(&lhist[k1 + 1], 1u);
+            }
         }
     }
     __syncthreads();
@@ -207,68 +218,79 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
         cursor[s] = (uint32_t)(segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s]);
     __syncthreads();
     const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
-    for (int64_t base = begin; base < end; base += 64) {
-        const int64_t i = base + lane;
-        int32_t k1 = -1;
-        bool has2 = false;
-        double px = 0.0, py = 0.0;
-        if (i < end) {
-            px = xyz[3 * i];
-            py = xyz[3 * i + 1];
-            windows_of(xyz[3 * i + 2], g, z_lo, z_hi, k1, has2);
+    for (int64_t sbase = begin; sbase < end; sbase += 64 * BIN_UNROLL) {
+        // the loads of BIN_UNROLL trips are issued together; the trips are then placed in order
+        double lx[BIN_UNROLL], ly[BIN_UNROLL], lz[BIN_UNROLL];
+#pragma unroll
+        for (int u = 0; u < BIN_UNROLL; u++) {
+            const int64_t i = sbase + 64 * u + lane;
+            const bool in = i < end;
+            lx[u] = in ? xyz[3 * i] : 0.0;
+            ly[u] = in ? xyz[3 * i + 1] : 0.0;
+            lz[u] = in ? xyz[3 * i + 2] : __longlong_as_double(0x7ff8000000000000ll);       // NaN: no window
         }
-        // key 0 = no window, key k+1 = window k
-        const uint32_t key = (uint32_t)(k1 + 1);
-        uint64_t bit_ballot[16];
-        for (int b = 0; b < nbits; b++)
-            bit_ballot[b] = __ballot((key >> b) & 1u);
-        const uint64_t twice = __ballot(has2);
-        uint64_t same = match_lanes(bit_ballot, nbits, key);
-        if (twice == 0ull) {
-            if (k1 >= 0) {
-                const int rank = __popcll(same & below), cnt = __popcll(same);
-                const uint32_t rel = cursor[k1];
-                if (rank == cnt - 1)
-                    cursor[k1] = rel + cnt;
-                const int64_t at = offsets[k1] + rel;
-                x_out[at + rank] = px;
-                y_out[at + rank] = py;
-                if (perm) perm[at + rank] = i;
-            }
-        } else {
-            // window k receives lanes with key1 == k and lanes with key1 == k-1 that lie in two windows
-            const uint64_t from_prev = match_lanes(bit_ballot, nbits, key - 1u) & twice;   // key-1 = window k1-1
-            const uint64_t to_next = match_lanes(bit_ballot, nbits, key + 1u);            // lanes in window k1+1
-            int64_t at1 = 0, at2 = 0;
-            int rank1 = 0, cnt1 = 0, rank2 = 0, cnt2 = 0;
-            if (k1 >= 0) {
-                const uint64_t grp1 = same | (key >= 2u ? from_prev : 0ull);
-                rank1 = __popcll(grp1 & below);
-                cnt1 = __popcll(grp1);
-                at1 = cursor[k1];               // (relative; the window's first slot is added below)
-                if (has2) {
-                    const uint64_t grp2 = to_next | (same & twice);
-                    rank2 = __popcll(grp2 & below);
-                    cnt2 = __popcll(grp2);
-                    at2 = cursor[k1 + 1];
+#pragma unroll
+        for (int u = 0; u < BIN_UNROLL; u++) {
+            if (sbase + 64 * u >= end)
+                break;
+            const int64_t i = sbase + 64 * u + lane;
+            int32_t k1;
+            bool has2;
+            const double px = lx[u], py = ly[u];
+            windows_of(lz[u], g, z_lo, z_hi, k1, has2);
+            // key 0 = no window, key k+1 = window k
+            const uint32_t key = (uint32_t)(k1 + 1);
+            uint64_t bit_ballot[16];
+            for (int b = 0; b < nbits; b++)
+                bit_ballot[b] = __ballot((key >> b) & 1u);
+            const uint64_t twice = __ballot(has2);
+            uint64_t same = match_lanes(bit_ballot, nbits, key);
+            if (twice == 0ull) {
+                if (k1 >= 0) {
+                    const int rank = __popcll(same & below), cnt = __popcll(same);
+                    const uint32_t rel = cursor[k1];
+                    if (rank == cnt - 1)
+                        cursor[k1] = rel + cnt;
+                    const int64_t at = offsets[k1] + rel;
+                    x_out[at + rank] = px;
+                    y_out[at + rank] = py;
+                    if (perm) perm[at + rank] = i;
                 }
-            }
-            // all reads of the cursors precede the writes (one wave, LDS ops in order)
-            if (k1 >= 0) {
-                if (rank1 == cnt1 - 1)
-                    cursor[k1] = (uint32_t)(at1 + cnt1);
-                if (has2 && rank2 == cnt2 - 1)
-                    cursor[k1 + 1] = (uint32_t)(at2 + cnt2);
-                at1 += offsets[k1];
-                if (has2)
-                    at2 += offsets[k1 + 1];
-                x_out[at1 + rank1] = px;
-                y_out[at1 + rank1] = py;
-                if (perm) perm[at1 + rank1] = i;
-                if (has2) {
-                    x_out[at2 + rank2] = px;
-                    y_out[at2 + rank2] = py;
-                    if (perm) perm[at2 + rank2] = i;
+            } else {
+                // window k receives lanes with key1 == k and lanes with key1 == k-1 that lie in two windows
+                const uint64_t from_prev = match_lanes(bit_ballot, nbits, key - 1u) & twice;   // key-1 = window k1-1
+                const uint64_t to_next = match_lanes(bit_ballot, nbits, key + 1u);            // lanes in window k1+1
+                int64_t at1 = 0, at2 = 0;
+                int rank1 = 0, cnt1 = 0, rank2 = 0, cnt2 = 0;
+                if (k1 >= 0) {
+                    const uint64_t grp1 = same | (key >= 2u ? from_prev : 0ull);
+                    rank1 = __popcll(grp1 & below);
+                    cnt1 = __popcll(grp1);
+                    at1 = cursor[k1];               // (relative; the window's first slot is added below)
+                    if (has2) {
+                        const uint64_t grp2 = to_next | (same & twice);
+                        rank2 = __popcll(grp2 & below);
+                        cnt2 = __popcll(grp2);
+                        at2 = cursor[k1 + 1];
+                    }
+                }
+                // all reads of the cursors precede the writes (one wave, LDS ops in order)
+                if (k1 >= 0) {
+                    if (rank1 == cnt1 - 1)
+                        cursor[k1] = (uint32_t)(at1 + cnt1);
+                    if (has2 && rank2 == cnt2 - 1)
+                        cursor[k1 + 1] = (uint32_t)(at2 + cnt2);
+                    at1 += offsets[k1];
+                    if (has2)
+                        at2 += offsets[k1 + 1];
+                    x_out[at1 + rank1] = px;
+                    y_out[at1 + rank1] = py;
+                    if (perm) perm[at1 + rank1] = i;
+                    if (has2) {
+                        x_out[at2 + rank2] = px;
+                        y_out[at2 + rank2] = py;
+                        if (perm) perm[at2 + rank2] = i;
+                    }
                 }
             }
         }
@@ -285,7 +307,7 @@ static BinPlan bin_plan(int64_t n, int64_t S)
     BinPlan p;
     const int64_t Sg = std::max<int64_t>(S, 1);
     int64_t chunks = std::max<int64_t>(1, (n + 4095) / 4096);
-    static const int64_t cap = [] { const char *e = getenv("PCFIT_BIN_CHUNKS"); return e ? atoll(e) : 2048ll; }();
+    static const int64_t cap = [] { const char *e = getenv("PCFIT_BIN_CHUNKS"); return e ? atoll(e) : 16384ll; }();
     chunks = std::min<int64_t>(chunks, std::min<int64_t>(cap, std::max<int64_t>(1, (32ll << 20) / Sg)));
     int64_t len = (n + chunks - 1) / std::max<int64_t>(chunks, 1);
     len = std::max<int64_t>(64, (len + 63) / 64 * 64);

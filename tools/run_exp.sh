@@ -1,5 +1,9 @@
+# scratch driver for timing experiments on the GPU box
 set -e
 cd $GRAFT_REPO_ROOT
-timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/t_gpu.log 2>&1 || { tail -40 gpurun_out/t_gpu.log; exit 1; }
-tail -3 gpurun_out/t_gpu.log
-timeout -k 10 300 python -u tools/exp_hull.py 2>&1 | grep -v amdgpu
+for S in 57 2000; do
+  for CH in 2048 8192 32768; do
+    echo "== S=$S chunks=$CH"
+    C4N=50000000 C4S=$S PCFIT_BIN_CHUNKS=$CH timeout -k 10 120 python3 -u tools/exp_all.py c4 2>&1 | grep -E "bin count|bin scatter"
+  done
+done
