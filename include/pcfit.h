@@ -294,6 +294,21 @@ int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z
                             double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
                             int64_t grid_len, int64_t cand_capacity);
 
+/* ---- the step before the path: XYZ text (host cores only, no GPU work) ---- */
+/* load_txt_points (utils/data_io.py:8-27; the GUI's loader gui.py:105-117 is the
+ * same rule without '//' and ';' comments) parsed by n_threads host threads
+ * (0 = one per core, at most 16).  text holds the file's bytes.  Lines made only of
+ * digits, signs, '.', 'e', 'E', commas and blanks are decided here (correctly
+ * rounded, like float()); comment lines are dropped; every other non-blank line is
+ * returned as a row with deferred[i] = 1 and {NaN, first byte, one past last byte}
+ * in rows, for the caller to judge by the literal rule.  rows capacity*3,
+ * deferred capacity, where capacity must be at least the number of lines
+ * (pcfit_count_text_lines; PCFIT_ERR_INVALID otherwise, *n_rows = the need);
+ * *n_rows receives the row count.  Rows keep file order. */
+int pcfit_count_text_lines(const char *text, size_t n_bytes, int32_t n_threads, int64_t *n_lines);
+int pcfit_parse_xyz_text(const char *text, size_t n_bytes, int32_t n_threads, double *rows, uint8_t *deferred,
+                         int64_t capacity, int64_t *n_rows);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,26 +8,45 @@ import os
 import numpy as np
 
 
-def load_txt_points(path: str) -> np.ndarray:
+def _parse_line(raw: str):
+    """One line by the reference's rule (utils/data_io.py:13-24): the point, or None."""
+    text = raw.strip()
+    if not text or text.startswith(("#", "//", ";")):
+        return None
+    fields = text.replace(",", " ").split()
+    if len(fields) < 3:
+        return None
+    try:
+        return float(fields[0]), float(fields[1]), float(fields[2])
+    except Exception:
+        return None
+
+
+def load_txt_points(path: str, n_threads: int = 0) -> np.ndarray:
     """Tolerant XYZ reader.  Reference: utils/data_io.py:8-27 - blank lines and
     lines starting with '#', '//' or ';' are skipped, commas count as blanks,
-    the first three fields must parse as floats, anything else is ignored."""
-    rows = []
-    with open(path, "r", encoding="utf-8", errors="ignore") as fh:
-        for raw in fh:
-            text = raw.strip()
-            if not text or text.startswith(("#", "//", ";")):
-                continue
-            fields = text.replace(",", " ").split()
-            if len(fields) < 3:
-                continue
-            try:
-                rows.append((float(fields[0]), float(fields[1]), float(fields[2])))
-            except Exception:
-                continue
-    if not rows:
+    the first three fields must parse as floats, anything else is ignored.
+    Plain numeric lines are parsed by the library on all host cores; lines with
+    any other content come back flagged and get the literal rule here."""
+    from .. import _ffi
+
+    with open(path, "rb") as fh:
+        data = fh.read()
+    rows, deferred = _ffi.parse_xyz_text(data, n_threads)
+    idx = np.flatnonzero(deferred)
+    if idx.size:
+        keep = np.ones(len(rows), bool)
+        for i in idx:
+            line = data[int(rows[i, 1]):int(rows[i, 2])].decode("utf-8", errors="ignore")
+            pt = _parse_line(line)
+            if pt is None:
+                keep[i] = False
+            else:
+                rows[i] = pt
+        rows = rows[keep]
+    if len(rows) == 0:
         raise RuntimeError("No valid XYZ lines found in TXT.")
-    return np.asarray(rows, dtype=np.float64)
+    return np.ascontiguousarray(rows, dtype=np.float64)
 
 
 def save_results(results: list, points: list, output_dir: str):

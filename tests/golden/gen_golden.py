@@ -282,7 +282,56 @@ def g_analyzer():
     save("analyzer", **out)
 
 
+# 12. text loader and CSV writers ------------------------------------------------
+TRICKY_LINES = [
+    b"# header comment", b"// another", b"; third kind", b"", b"   ", b"1 2 3", b"1.5,2.5,3.5", b" 4.0 , 5.0 ,6.0  ",
+    b"7\t8\t9\t10 11 12", b"1e3 -2E-2 +3.25e+1", b".5 5. -.25", b"+1 -0 00012.50", b"1 2", b"1 2 x", b"a b c",
+    b"1 2 3 label", b"nan inf -inf", b"NaN Infinity +INF", b"1_000 2 3", b"1__0 2 3", b"0x10 2 3", b"1e999 -1e999 1e-999",
+    b"4.9e-324 2.2250738585072014e-308 1.7976931348623157e308", b"1e 2 3", b"1e+ 2 3", b"+-1 2 3", b"--1 2 3",
+    b"1..2 2 3", b"1.2.3 2 3", b"- 2 3 4", b". 2 3", b"e5 2 3", b"1,,2,,3", b",1,2,3,", b"1;2;3", b"#1 2 3", b" # 1 2 3",
+    b"//1 2 3", b"/ 1 2 3", b"1 2 3 // trailing", b"1 2 3 # trailing", b"\xc2\xa01 2 3\xc2\xa0", b"\xff1 2 3",
+    b"\xef\xbb\xbf1 2 3", b"1\x0b2\x0c3", b"\x1c1 2 3", b"\x1c# c", b"1\x002 3 4", b"\xd9\xa1 \xd9\xa2 \xd9\xa3",
+    b"0.1 0.2 0.30000000000000004", b"123456789012345678901234567890 1e-5 3", b"9007199254740993 2 3",
+    b"1.0000000000000002220446049250313080847263336181640625 2 3", b"3 4 5\r6 7 8\r\n9 10 11", b"12 13 14",
+]
+
+
+def g_data_io():
+    from utils import data_io as rio         # (reference)
+    import contextlib
+    import io
+    text = b"\n".join(TRICKY_LINES) + b"\n15 16 17"           # last line without a terminator
+    rng = np.random.default_rng(9)
+    bulk = rng.normal(0, 100, (2000, 3))
+    text += b"\n" + "\n".join(" ".join(repr(float(v)) for v in row) for row in bulk).encode()
+    d = tempfile.mkdtemp(prefix="pcfit_io_")
+    path = os.path.join(d, "scan.txt")
+    with open(path, "wb") as fh:
+        fh.write(text)
+    pts = rio.load_txt_points(path)
+    out = dict(text=np.frombuffer(text, np.uint8), points=pts)
+    # writers: the analyzer golden's scan, results and edge frames through save_results
+    scan = make_cylinder(50_000, 20, seed=5, outlier_frac=0.02)
+    az = ran.CylinderAnalyzer(ran.Config(z_step=2.0, min_points_per_slice=1000))
+    results, frames = [], []
+    for zc in az.calculate_z_centers(scan)[:4]:
+        pack, edge, warn = az.process_slice(scan, zc)
+        results.append(pack[0])
+        frames.append(edge)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rio.save_results(results, frames, d)
+    out["results_csv"] = np.frombuffer(open(os.path.join(d, "slice_results.csv"), "rb").read(), np.uint8)
+    out["points_csv"] = np.frombuffer(open(os.path.join(d, "slice_points.csv"), "rb").read(), np.uint8)
+    save("data_io", **out)
+
+
 if __name__ == "__main__":
+    only = sys.argv[2:]
+    if only:
+        for name in only:
+            globals()["g_" + name]()
+        sys.exit(0)
+    g_data_io()
     g_choice3()
     g_circle3()
     g_kasa_lm()
