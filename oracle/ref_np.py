@@ -501,3 +501,22 @@ def make_slices(slices, per_slice, seed, radius=10.0, centre=(3.0, -2.0), sigma=
     y = centre[1] + shift[sid, 1] + r * np.sin(ang)
     offsets = np.arange(slices + 1, dtype=np.int64) * per_slice
     return x, y, offsets
+
+
+def year_boundary_rows(results, year, thickness):
+    """Rows of year_{Y}_boundary_data.csv, built one by one as gui.py:1391-1436 does."""
+    rows = []
+    for result in results:
+        cx, cy, R = result['cx'], result['cy'], result['R']
+        if 'boundary_points' in result and result['boundary_points']:
+            b = np.array(result['boundary_points'])
+            dx, dy = b[:, 0] - cx, b[:, 1] - cy
+            delta_r = np.hypot(dx, dy) - R
+            theta = (np.arctan2(dy, dx) + 2 * np.pi) % (2 * np.pi)
+            for i, (t, d) in enumerate(zip(theta, delta_r)):
+                rows.append(dict(year=year, z_center=result['z_center'], cx=cx, cy=cy, R=R, thickness=thickness,
+                                 theta=t, delta_r=d, boundary_point_index=i))
+        else:
+            rows.append(dict(year=year, z_center=result['z_center'], cx=cx, cy=cy, R=R, thickness=thickness,
+                             theta=np.nan, delta_r=np.nan, boundary_point_index=0))
+    return rows

@@ -181,19 +181,27 @@ __global__ __launch_bounds__(RS_BLOCK) void ransac_score_kernel(
             count += in;
         }
     } else {
-        int64_t i = 0;
-        for (; i + 8 <= n; i += 8) {
+        // count += in, as one add-with-carry whose carry-in is the compare mask (a lane per hypothesis)
+        // (the two compare masks are combined as scalars: a bool built from both would be made a
+        // vector value first)
+        auto tally = [&](double d2) {
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(d2 >= d_lo) & __builtin_amdgcn_ballot_w64(d2 <= d_hi);
+            asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(count) : "s"(m) : "vcc");
+        };
+        const int32_t n32 = (int32_t)n;                 // slices hold fewer than 2^31 points: the score is an int32
+        int32_t i = 0;
+        for (; i + 8 <= n32; i += 8) {
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const double dx = xs[i + k] - cx, dy = ys[i + k] - cy;
                 const double d2 = dx * dx + dy * dy;
-                count += (d2 >= d_lo) & (d2 <= d_hi);
+                tally(d2);
             }
         }
-        for (; i < n; i++) {
+        for (; i < n32; i++) {
             const double dx = xs[i] - cx, dy = ys[i] - cy;
             const double d2 = dx * dx + dy * dy;
-            count += (d2 >= d_lo) & (d2 <= d_hi);
+            tally(d2);
         }
     }
     unsigned long long key = 0;

@@ -651,3 +651,39 @@ def test_scan_level_call_matches_bin_then_hybrid():
     # candidate arrays that are too small are grown and the call repeated
     c = F.scan_hybrid_batch(pts, zc - 1.0, zc + 1.0, cand_capacity=7)
     assert np.array_equal(c["cand_x"], a["cand_x"]) and np.array_equal(c["fit"], a["fit"], equal_nan=True)
+
+
+def test_year_export_files_and_matcher(tmp_path):
+    """year_{Y}_boundary_data.csv / year_{Y}_summary.csv against the row-by-row restatement of
+    gui.py:1388-1459 written with the same pandas call; the reference's GUI code cannot be
+    imported (PyQt6 absent), so this format is pinned by the restatement only."""
+    import pandas as pd
+    from pointcloud_amd import Config, CylinderAnalyzer
+    from pointcloud_amd.synth import make_cylinder
+    from pointcloud_amd.utils.year_export import export_year_data, match_year_slices
+    pts = make_cylinder(60_000, 12, seed=21, outlier_frac=0.02)
+    results = CylinderAnalyzer(Config(min_points_per_slice=500)).analyze_with_progress(pts)
+    results.append(dict(results[0], z_center=99.0, boundary_points=[]))          # a slice without boundary points
+    bpath, spath = export_year_data(results, " 2023 ", 2.0, str(tmp_path))
+    assert bpath.endswith("year_2023_boundary_data.csv") and spath.endswith("year_2023_summary.csv")
+    want = pd.DataFrame(R.year_boundary_rows(results, "2023", 2.0))
+    got = pd.read_csv(bpath)
+    assert list(got.columns) == list(want.columns) and len(got) == len(want)
+    for col in want.columns:
+        if col == "year":
+            assert (got[col].astype(str) == "2023").all()
+        else:
+            # '%.6f' text of values that agree to an ulp: equal up to one unit of the last printed digit
+            assert np.allclose(got[col].to_numpy(float), want[col].to_numpy(float), rtol=0, atol=1.01e-6,
+                               equal_nan=True), col
+    ref_text = want.to_csv(index=False, float_format="%.6f").splitlines()
+    got_text = open(bpath).read().splitlines()
+    assert sum(a != b for a, b in zip(ref_text, got_text)) <= len(ref_text) // 1000
+    summ = pd.read_csv(spath)
+    assert list(summ.columns) == ["year", "z_center", "cx", "cy", "R", "thickness", "ovality_pct", "n_boundary_points"]
+    assert summ["n_boundary_points"].tolist() == [len(r["boundary_points"]) for r in results]
+    year, rows = match_year_slices(bpath, results[3]["z_center"] + 4e-4, 2.0)
+    assert year == "2023" and len(rows) == len(results[3]["boundary_points"])
+    assert np.all(np.diff(rows["theta"].to_numpy()) >= 0)
+    assert match_year_slices(bpath, results[3]["z_center"] + 0.5, 2.0) is None
+    assert match_year_slices(pd.DataFrame({"z_center": [1.0]}), 1.0, 2.0) is None

@@ -33,7 +33,7 @@ if "c3" in which:
     model, score, best, mask, status = E(S, 3), E(S, dt=torch.int32), E(S, dt=torch.int32), E(S * n, dt=torch.uint8), E(S, dt=torch.int32)
     ws = E(S, dt=torch.int64)
     pts_hyp = S * n * T
-    timeit("C3 ransac 10k x 8192 x 1024 hyp", lambda: F.check(L.pcfit_ransac_batch_dev(p(x), p(y), p(off), S, 0.5, T, 0.1, None, p(dtab), p(dof), p(model), p(score), p(best), p(mask), p(status), p(ws), S * 8, st)), reps=3, units=(pts_hyp / 1e3, "G point-hyp/s"))
+    timeit("C3 ransac 10k x 8192 x 1024 hyp", lambda: F.check(L.pcfit_ransac_batch_dev(p(x), p(y), p(off), S, 0.5, T, 0.1, None, p(dtab), p(dof), p(model), p(score), p(best), p(mask), p(status), p(ws), S * 8, st)), reps=3, units=(pts_hyp / 1e3, "T point-hyp/s"))
     del x, y, mask
 
 if "c4" in which:
