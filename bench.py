@@ -52,7 +52,7 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def cpu_baseline(x, y, off, bins, lo, hi, budget_s=12.0, max_slices=400):
+def cpu_baseline(x, y, off, bins, lo, hi, budget_s=14.0, max_slices=2000):
     """numpy restatement of the same step (Kasa -> LM -> residual histogram), slice after slice,
     on the host: the stand-in for the reference's CPU path, which cannot travel."""
     from oracle import ref_np as R
@@ -72,7 +72,7 @@ def cpu_baseline(x, y, off, bins, lo, hi, budget_s=12.0, max_slices=400):
     return pts / dt, done, dt
 
 
-def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=24):
+def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600):
     from oracle import native as N
     n_slices = min(n_slices, len(off) - 1)
     end = off[n_slices]

@@ -60,9 +60,10 @@ class CylinderAnalyzer:
                               want_unique=False)
         return offsets, x, y, h
 
-    def _slice_result(self, s: int, z_center, n0: int, h: dict):
+    def _slice_result(self, s: int, z_center, n0: int, h: dict, want_ov: bool = True):
         """Result dict, edge frame columns and the ovality dict of slice ``s``
-        (reference: analyzer.py:77-127)."""
+        (reference: analyzer.py:77-127).  ``want_ov=False`` leaves out the two
+        profile arrays of the ovality dict (the batch drivers do not return it)."""
         dz = self.config.z_step / 2.0
         c0, c1 = int(h["cand_offsets"][s]), int(h["cand_offsets"][s + 1])
         cand = np.stack([h["cand_x"][c0:c1], h["cand_y"][c0:c1]], axis=1)
@@ -73,9 +74,10 @@ class CylinderAnalyzer:
         ov = {
             "Rmax": np.float64(ovs[0]), "Rmin": np.float64(ovs[1]),
             "ovality_abs": np.float64(ovs[2]), "ovality_pct": np.float64(ovs[3]), "k2_amp": np.float64(ovs[4]),
-            "theta": np.linspace(0, 2 * np.pi, K, endpoint=False),
-            "dev_uniform": None if h["dev_uniform"] is None else h["dev_uniform"][s, :K],
         }
+        if want_ov:
+            ov["theta"] = np.linspace(0, 2 * np.pi, K, endpoint=False)
+            ov["dev_uniform"] = None if h["dev_uniform"] is None else h["dev_uniform"][s, :K]
         result = {
             "z_center": z_center,
             "z_low": z_center - dz,
@@ -170,7 +172,7 @@ class CylinderAnalyzer:
                 yield None, None, f"SKIP zc={zc:.3f}: hybrid fit failed"
                 continue
             n0 = min(n0, self.config.max_points_for_speed)
-            result, _, _, _, edge = self._slice_result(s, zc, n0, h)
+            result, _, _, _, edge = self._slice_result(s, zc, n0, h, want_ov=False)
             yield result, (edge if want_edges else None), None
 
     def analyze_with_progress(self, points: np.ndarray, progress_callback=None):
