@@ -60,6 +60,12 @@ int pcfit_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *st
 int pcfit_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int pcfit_memset(void *dst_dev, int value, size_t bytes, void *stream);
 int pcfit_stream_synchronize(void *stream);
+/* The host-pointer entry points keep the device blocks they allocated for the
+ * next call (per device, at most PCFIT_POOL_BYTES bytes from the environment,
+ * default 16 GiB; first use of fresh device memory costs more than the kernels).
+ * This gives every cached block back to the driver.  No counterpart in the
+ * reference; the _dev entry points never allocate and are not concerned. */
+int pcfit_release_cache(void);
 
 /* ---- RANSAC sampling tables (host side, exact integer work) --------- */
 /* PCG64 state numpy's default_rng(seed) starts from: state_hi, state_lo,
@@ -210,8 +216,9 @@ int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t 
 /* ---- ovality + k=2 Fourier amplitude: ovality_and_fourier, boundary.py:56-90 */
 /* scal: S*5 = Rmax, Rmin, ovality_abs, ovality_pct, k2_amp (NaN for an empty
  * slice or a NaN circle).  dev_uniform (nullable): row s holds the deviation
- * profile resampled on K_s = max(1024, n_s) uniform angles; rows are grid_len
- * apart, grid_len >= max(1024, longest slice).  Slices of at most 8192 points. */
+ * profile resampled on K_s = max(1024, n_s) uniform angles, NaN from K_s to the
+ * end of the row; rows are grid_len apart, grid_len >= max(1024, longest slice).
+ * Slices of at most 8192 points. */
 int pcfit_ovality_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                             int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
                             int64_t grid_len, void *stream);
@@ -308,6 +315,26 @@ int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z
 int pcfit_count_text_lines(const char *text, size_t n_bytes, int32_t n_threads, int64_t *n_lines);
 int pcfit_parse_xyz_text(const char *text, size_t n_bytes, int32_t n_threads, double *rows, uint8_t *deferred,
                          int64_t capacity, int64_t *n_rows);
+
+/* ---- a scan that stays on the device --------------------------------- */
+/* The reference keeps one scan in memory and analyses it again and again (the
+ * GUI's Analyze button with new parameters, visualize_slice: gui.py:31,1500).
+ * pcfit_scan_upload copies xyz (n_points*3, row-major) to the current device
+ * once and, if z_min_max is given, stores numpy's points[:,2].min() and .max()
+ * there (analyzer.py:236: what calculate_z_centers needs; both NaN if any z is
+ * NaN, or if the scan is empty); pcfit_scan_hybrid_resident is
+ * pcfit_scan_hybrid_batch on that copy; pcfit_scan_free releases it (to the
+ * block cache).  A handle belongs to the device it was made on. */
+typedef struct pcfit_scan pcfit_scan;
+int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan **scan, double *z_min_max);
+int pcfit_scan_free(pcfit_scan *scan);
+int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
+                               double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
+                               double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets,
+                               int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets,
+                               double *cand_x, double *cand_y, uint8_t *mask, double *radius, double *theta,
+                               int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
+                               int64_t cand_capacity);
 
 #ifdef __cplusplus
 }

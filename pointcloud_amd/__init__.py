@@ -7,5 +7,6 @@ The modules mirror the reference's layout and call signatures
 (include/pcfit.h) to hand-written HIP kernels.  There is no CPU fallback.
 """
 from .analyzer import Config, CylinderAnalyzer  # noqa: F401
+from ._ffi import DeviceScan  # noqa: F401
 
-__all__ = ["Config", "CylinderAnalyzer"]
+__all__ = ["Config", "CylinderAnalyzer", "DeviceScan"]

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pcfit_memcpy_d2h": (C.c_int, [_vp, _vp, _sz, _vp]),
     "pcfit_memset": (C.c_int, [_vp, C.c_int, _sz, _vp]),
     "pcfit_stream_synchronize": (C.c_int, [_vp]),
+    "pcfit_release_cache": (C.c_int, []),
     "pcfit_seed_state": (C.c_int, [_u64, _vp]),
     "pcfit_choice3_table": (C.c_int, [_vp, _i64, _i32, _vp]),
     "pcfit_bin_workspace_bytes": (_sz, [_i64, _i64]),
@@ -85,6 +86,10 @@ SIGNATURES = {
                            + [_i64]),
     "pcfit_count_text_lines": (C.c_int, [C.c_char_p, _sz, _i32, _vp]),
     "pcfit_parse_xyz_text": (C.c_int, [C.c_char_p, _sz, _i32, _vp, _vp, _i64, _vp]),
+    "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
+    "pcfit_scan_free": (C.c_int, [_vp]),
+    "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
+                                   + [_vp] * 13 + [_i64, _i64]),
     "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
                                 + [_vp] * 13 + [_i64, _i64]),
 }
@@ -223,8 +228,8 @@ def bin_slices(points, z_lo, z_hi, want_perm=True):
     S = z_lo.size
     cap = 2 * pts.shape[0] + 1
     offsets = np.zeros(S + 1, np.int64)
-    xo, yo = np.zeros(cap), np.zeros(cap)
-    perm = np.zeros(cap, np.int64) if want_perm else None
+    xo, yo = np.empty(cap), np.empty(cap)
+    perm = np.empty(cap, np.int64) if want_perm else None
     total = C.c_int64(0)
     check(lib().pcfit_bin_slices(_p(pts), pts.shape[0], _p(z_lo), _p(z_hi), S, _p(offsets), _p(xo), _p(yo), _p(perm),
                                  cap, C.addressof(total)))
@@ -306,18 +311,57 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
                 argmax=amm[:, 0], argmin=amm[:, 1], ov=ov, dev_uniform=dev, grid_len=K)
 
 
+class DeviceScan:
+    """A scan uploaded once and kept on the GPU (pcfit_scan_upload): ``n_points``, and ``z_min`` / ``z_max``
+    as numpy's ``points[:, 2].min()`` / ``.max()``.  Free it with ``close()`` (or let it go out of scope)."""
+
+    def __init__(self, points):
+        pts = _arr(points, np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must be (N,3)")
+        self.n_points = int(pts.shape[0])
+        self._handle = _vp()
+        zr = np.full(2, np.nan)
+        check(lib().pcfit_scan_upload(_p(pts), self.n_points, C.byref(self._handle), _p(zr)))
+        self.z_min, self.z_max = float(zr[0]), float(zr[1])
+
+    def close(self):
+        if getattr(self, "_handle", None):
+            lib().pcfit_scan_free(self._handle)
+            self._handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self):
+        return self.n_points
+
+
 def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
                       huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None):
-    """bin_slices + hybrid_batch without the round trip of the binned points: the scan is uploaded once and
-    only per-slice results and candidates come back.  With hull candidates the candidate arrays start small
-    and the call is repeated once with the needed size if they were too small."""
-    pts = _arr(points, np.float64)
-    if pts.ndim != 2 or pts.shape[1] != 3:
-        raise ValueError("points must be (N,3)")
+    """bin_slices + hybrid_batch without the round trip of the binned points: the scan (an (N,3) array, uploaded
+    for this call, or a DeviceScan already on the GPU) is binned on the device and only per-slice results and
+    candidates come back.  With hull candidates the candidate arrays start small and the call is repeated once
+    with the needed size if they were too small."""
+    if isinstance(points, DeviceScan):
+        if not points._handle:
+            raise PcfitError("the DeviceScan was closed")
+        N = points.n_points
+        head = (lib().pcfit_scan_hybrid_resident, (points._handle,))
+    else:
+        pts = _arr(points, np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must be (N,3)")
+        N = pts.shape[0]
+        head = (lib().pcfit_scan_hybrid_batch, (_p(pts), N))
     z_lo = _arr(z_lo, np.float64)
     z_hi = _arr(z_hi, np.float64)
     S = z_lo.size
-    N = pts.shape[0]
     if cand_capacity is None:
         cand_capacity = 2 * N if not use_hull else min(2 * N, max(1 << 20, 1024 * S))
     rr = None if r_range is None else _arr(r_range, np.float64)
@@ -329,16 +373,15 @@ def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_i
         fit = np.full((S, 3), np.nan)
         n_unique = np.zeros(S, np.int64)
         cand_off = np.zeros(S + 1, np.int64)
-        cx_, cy_ = np.zeros(cap), np.zeros(cap)
-        mask = np.zeros(cap, np.uint8)
-        radius, theta = np.zeros(cap), np.zeros(cap)
+        cx_, cy_ = np.empty(cap), np.empty(cap)
+        mask = np.empty(cap, np.uint8)
+        radius, theta = np.empty(cap), np.empty(cap)
         amm = np.zeros((S, 2), np.int64)
         ov = np.zeros((S, 5))
         dev = np.full((S, K), np.nan) if want_profile else None
-        rc = lib().pcfit_scan_hybrid_batch(_p(pts), N, _p(z_lo), _p(z_hi), S, inlier_tol, max_trials,
-                                           min_inliers_frac, _p(rr), huber_delta, 1 if use_hull else 0, int(seed),
-                                           _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off), _p(cx_),
-                                           _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
+        rc = head[0](*head[1], _p(z_lo), _p(z_hi), S, inlier_tol, max_trials, min_inliers_frac, _p(rr), huber_delta,
+                     1 if use_hull else 0, int(seed), _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off),
+                     _p(cx_), _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
         if rc != 0 and int(cand_off[-1]) > cap:           # candidate arrays too small: the count is known now
             cand_capacity = int(cand_off[-1])
             continue

@@ -179,23 +179,31 @@ class CylinderAnalyzer:
         """Analyze points with progress reporting (reference: analyzer.py:181-230).
         All windows run in one GPU batch; the callback then receives the same
         integer percentages the reference's thread pool would emit."""
-        if not isinstance(points, np.ndarray):
-            points = np.array(points)
+        if isinstance(points, _ffi.DeviceScan):
+            # a scan already on the GPU; a configured z range would have to filter it, which needs the array
+            if self.z_min is not None and self.z_max is not None:
+                raise ValueError("a DeviceScan cannot be combined with Config.z_min / z_max: pass the array")
+        else:
+            if not isinstance(points, np.ndarray):
+                points = np.array(points)
 
-        if points.ndim != 2 or points.shape[1] != 3:
-            raise ValueError("Points must be Nx3 array")
+            if points.ndim != 2 or points.shape[1] != 3:
+                raise ValueError("Points must be Nx3 array")
 
-        if self.z_min is not None and self.z_max is not None:
-            mask = (points[:, 2] >= self.z_min) & (points[:, 2] <= self.z_max)
-            points = points[mask]
-            if len(points) == 0:
-                raise ValueError(f"No points in specified Z range [{self.z_min}, {self.z_max}]")
+            if self.z_min is not None and self.z_max is not None:
+                mask = (points[:, 2] >= self.z_min) & (points[:, 2] <= self.z_max)
+                points = points[mask]
+                if len(points) == 0:
+                    raise ValueError(f"No points in specified Z range [{self.z_min}, {self.z_max}]")
+            elif len(points) > 0:
+                # upload once; the z range comes back from the device instead of two strided host passes
+                points = _ffi.DeviceScan(points)
 
         results = []
         z_centers = self.calculate_z_centers(points)
         total = len(z_centers)
         done = 0
-        for res, _, warn in self._analyze_windows(np.ascontiguousarray(points, dtype=np.float64), z_centers):
+        for res, _, warn in self._analyze_windows(points, z_centers):
             if warn is None:
                 results.append(res)
             done += 1
@@ -209,6 +217,8 @@ class CylinderAnalyzer:
         """Calculate z-centers for slicing (reference: analyzer.py:232-243)."""
         if self.z_min is not None and self.z_max is not None:
             z_min, z_max = self.z_min, self.z_max
+        elif isinstance(points, _ffi.DeviceScan):
+            z_min, z_max = np.float64(points.z_min), np.float64(points.z_max)
         else:
             z_min, z_max = points[:, 2].min(), points[:, 2].max()
 

@@ -3,8 +3,11 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "pcfit_internal.h"
@@ -98,6 +101,115 @@ static void choice3_table(const uint64_t st[4], int64_t n, int32_t trials, int32
     }
 }
 
+
+// ---- cache of device blocks for the host-pointer entry points ----
+// All of them work on the null stream and synchronise it before they return, and work queued there
+// by a later call runs after whatever an earlier call left in flight, so a block can be handed out again
+// as soon as its DevBuf is gone.
+namespace {
+struct PoolBlock {
+    void *p;
+    size_t bytes;
+};
+constexpr int POOL_MAX_DEV = 64;
+std::mutex g_pool_mu;
+std::vector<PoolBlock> g_pool[POOL_MAX_DEV];
+size_t g_pool_bytes[POOL_MAX_DEV];
+
+size_t pool_cap()
+{
+    static const size_t cap = [] {
+        const char *e = getenv("PCFIT_POOL_BYTES");
+        return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)16 << 30);
+    }();
+    return cap;
+}
+bool pool_poison()
+{
+    static const bool on = [] { const char *e = getenv("PCFIT_POOL_POISON"); return e && *e == '1'; }();
+    return on;
+}
+void pool_drop(int dev)
+{
+    for (const PoolBlock &b : g_pool[dev])
+        (void)hipFree(b.p);
+    g_pool[dev].clear();
+    g_pool_bytes[dev] = 0;
+}
+}  // namespace
+
+int pool_get(size_t bytes, void **ptr, size_t *got)
+{
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    const size_t need = std::max<size_t>(256, (bytes + 255) & ~(size_t)255);
+    if (dev >= 0 && dev < POOL_MAX_DEV) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        std::vector<PoolBlock> &v = g_pool[dev];
+        int best = -1;
+        for (int i = 0; i < (int)v.size(); i++)
+            if (v[i].bytes >= need && v[i].bytes <= 2 * need + (1u << 20) && (best < 0 || v[i].bytes < v[best].bytes))
+                best = i;
+        if (best >= 0) {
+            *ptr = v[best].p;
+            *got = v[best].bytes;
+            g_pool_bytes[dev] -= v[best].bytes;
+            v.erase(v.begin() + best);
+            if (pool_poison())
+                PCFIT_HIP(hipMemsetAsync(*ptr, 0xff, *got, nullptr));
+            return PCFIT_OK;
+        }
+    }
+    hipError_t e = hipMalloc(ptr, need);
+    if (e == hipErrorOutOfMemory && dev >= 0 && dev < POOL_MAX_DEV) {
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mu);
+            pool_drop(dev);                      // give the cached blocks back and try once more
+        }
+        e = hipMalloc(ptr, need);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        set_error("hipMalloc of %zu bytes failed: %s", need, hipGetErrorString(e));
+        return PCFIT_ERR_HIP;
+    }
+    *got = need;
+    if (pool_poison())
+        PCFIT_HIP(hipMemsetAsync(*ptr, 0xff, need, nullptr));
+    return PCFIT_OK;
+}
+
+void pool_put(void *ptr, size_t bytes)
+{
+    if (!ptr)
+        return;
+    int dev = -1;
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) == hipSuccess)
+        dev = attr.device;
+    else
+        (void)hipGetLastError();
+    if (dev >= 0 && dev < POOL_MAX_DEV) {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (g_pool_bytes[dev] + bytes <= pool_cap()) {
+            g_pool[dev].push_back({ptr, bytes});
+            g_pool_bytes[dev] += bytes;
+            return;
+        }
+    }
+    (void)hipFree(ptr);
+}
+
+int pool_release()
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (int d = 0; d < POOL_MAX_DEV; d++)
+        pool_drop(d);
+    return PCFIT_OK;
+}
+
 }  // namespace pcfit
 
 using namespace pcfit;
@@ -105,6 +217,8 @@ using namespace pcfit;
 // ------------------------------------------------------------------ plumbing
 PCFIT_API int pcfit_version(void) { return 100; }
 PCFIT_API const char *pcfit_last_error(void) { return g_err; }
+
+PCFIT_API int pcfit_release_cache(void) { return pool_release(); }
 
 PCFIT_API int pcfit_device_count(int *count)
 {
@@ -119,32 +233,38 @@ PCFIT_API int pcfit_set_device(int device)
 }
 PCFIT_API int pcfit_malloc(void **ptr, size_t bytes)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(ptr, "ptr is null");
     PCFIT_HIP(hipMalloc(ptr, bytes ? bytes : 8));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_free(void *ptr)
 {
+    PCFIT_ENTER();
     if (ptr) PCFIT_HIP(hipFree(ptr));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream)
 {
+    PCFIT_ENTER();
     if (bytes) PCFIT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream)
 {
+    PCFIT_ENTER();
     if (bytes) PCFIT_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_memset(void *dst, int value, size_t bytes, void *stream)
 {
+    PCFIT_ENTER();
     if (bytes) PCFIT_HIP(hipMemsetAsync(dst, value, bytes, as_stream(stream)));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_stream_synchronize(void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_HIP(hipStreamSynchronize(as_stream(stream)));
     return PCFIT_OK;
 }
@@ -222,6 +342,7 @@ static bool use_split(int64_t max_len, int64_t n_slices)
 PCFIT_API int pcfit_kasa_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                double *cxcyr, int32_t *status)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -256,6 +377,7 @@ PCFIT_API int pcfit_lm_batch(const double *x, const double *y, const int64_t *of
                              const double *init, double huber_delta, int32_t max_iter, double lm_lambda0,
                              double tol_update, double tol_cost, double *out, int32_t *iters)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -291,6 +413,7 @@ PCFIT_API int pcfit_ransac_batch(const double *x, const double *y, const int64_t
                                  uint64_t seed, double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
                                  int32_t *status)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -342,6 +465,7 @@ PCFIT_API int pcfit_residuals_batch(const double *x, const double *y, const int6
                                     const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
                                     const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -389,6 +513,7 @@ PCFIT_API int pcfit_residuals_batch(const double *x, const double *y, const int6
 PCFIT_API int pcfit_angle_max_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                     const double *cxcyr, int32_t bins, int64_t *sel)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;

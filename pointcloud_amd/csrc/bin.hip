@@ -367,6 +367,7 @@ PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const dou
                                   int64_t n_slices, const double *window_geom, int64_t *offsets, void *workspace,
                                   size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     if (n_slices > BIN_MAX_SLICES) {
         set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)n_slices);
@@ -407,6 +408,7 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
                                     double *x_out, double *y_out, int64_t *perm, void *workspace,
                                     size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1 && n_slices <= BIN_MAX_SLICES, "bin: bad sizes");
     PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && x_out && y_out && (xyz || n_points == 0),
                   "bin: null pointer");
@@ -435,56 +437,37 @@ PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double
                                int64_t n_slices, int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
                                int64_t capacity, int64_t *total)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     PCFIT_REQUIRE(z_lo && z_hi && offsets && total && (xyz || n_points == 0), "bin: null pointer");
     double geom[3];
     PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
     hipStream_t st = nullptr;
-    void *d_xyz = nullptr, *d_lo = nullptr, *d_hi = nullptr, *d_off = nullptr, *d_ws = nullptr, *d_x = nullptr,
-         *d_y = nullptr, *d_perm = nullptr;
-    int rc = PCFIT_OK;
+    DevBuf dxyz, dlo, dhi, doff, dws, dx, dy, dperm;
     const size_t ws_bytes = pcfit_bin_workspace_bytes(n_points, n_slices);
-    auto cleanup = [&]() {
-        for (void *p : {d_xyz, d_lo, d_hi, d_off, d_ws, d_x, d_y, d_perm})
-            if (p) (void)hipFree(p);
-    };
-#define BIN_TRY(expr)                 \
-    do {                              \
-        rc = (expr);                  \
-        if (rc != PCFIT_OK) {         \
-            cleanup();                \
-            return rc;                \
-        }                             \
-    } while (0)
-    BIN_TRY(pcfit_malloc(&d_xyz, (size_t)n_points * 24));
-    BIN_TRY(pcfit_malloc(&d_lo, (size_t)n_slices * 8));
-    BIN_TRY(pcfit_malloc(&d_hi, (size_t)n_slices * 8));
-    BIN_TRY(pcfit_malloc(&d_off, (size_t)(n_slices + 1) * 8));
-    BIN_TRY(pcfit_malloc(&d_ws, ws_bytes));
-    BIN_TRY(pcfit_memcpy_h2d(d_xyz, xyz, (size_t)n_points * 24, st));
-    BIN_TRY(pcfit_memcpy_h2d(d_lo, z_lo, (size_t)n_slices * 8, st));
-    BIN_TRY(pcfit_memcpy_h2d(d_hi, z_hi, (size_t)n_slices * 8, st));
-    BIN_TRY(pcfit_bin_count_dev((const double *)d_xyz, n_points, (const double *)d_lo, (const double *)d_hi, n_slices,
-                                geom, (int64_t *)d_off, d_ws, ws_bytes, st));
-    BIN_TRY(pcfit_memcpy_d2h(offsets, d_off, (size_t)(n_slices + 1) * 8, st));
-    BIN_TRY(pcfit_stream_synchronize(st));
+    PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
+    PCFIT_TRY(dlo.upload(z_lo, (size_t)n_slices * 8, st));
+    PCFIT_TRY(dhi.upload(z_hi, (size_t)n_slices * 8, st));
+    PCFIT_TRY(doff.alloc((size_t)(n_slices + 1) * 8));
+    PCFIT_TRY(dws.alloc(ws_bytes));
+    PCFIT_TRY(pcfit_bin_count_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
+                                  doff.as<int64_t>(), dws.p, dws.bytes, st));
+    PCFIT_TRY(doff.download(offsets, (size_t)(n_slices + 1) * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
     *total = offsets[n_slices];
     if (*total > capacity || ((x_out == nullptr || y_out == nullptr) && *total > 0)) {
-        cleanup();
         set_error("bin: outputs hold %lld points, %lld needed", (long long)capacity, (long long)*total);
         return PCFIT_ERR_INVALID;
     }
-    BIN_TRY(pcfit_malloc(&d_x, (size_t)*total * 8));
-    BIN_TRY(pcfit_malloc(&d_y, (size_t)*total * 8));
-    if (perm) BIN_TRY(pcfit_malloc(&d_perm, (size_t)*total * 8));
-    BIN_TRY(pcfit_bin_scatter_dev((const double *)d_xyz, n_points, (const double *)d_lo, (const double *)d_hi,
-                                  n_slices, geom, (const int64_t *)d_off, (double *)d_x, (double *)d_y, (int64_t *)d_perm,
-                                  d_ws, ws_bytes, st));
-    BIN_TRY(pcfit_memcpy_d2h(x_out, d_x, (size_t)*total * 8, st));
-    BIN_TRY(pcfit_memcpy_d2h(y_out, d_y, (size_t)*total * 8, st));
-    if (perm) BIN_TRY(pcfit_memcpy_d2h(perm, d_perm, (size_t)*total * 8, st));
-    BIN_TRY(pcfit_stream_synchronize(st));
-#undef BIN_TRY
-    cleanup();
+    PCFIT_TRY(dx.alloc((size_t)*total * 8));
+    PCFIT_TRY(dy.alloc((size_t)*total * 8));
+    if (perm) PCFIT_TRY(dperm.alloc((size_t)*total * 8));
+    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
+                                    doff.as<int64_t>(), dx.as<double>(), dy.as<double>(),
+                                    perm ? dperm.as<int64_t>() : nullptr, dws.p, dws.bytes, st));
+    PCFIT_TRY(dx.download(x_out, (size_t)*total * 8, st));
+    PCFIT_TRY(dy.download(y_out, (size_t)*total * 8, st));
+    if (perm) PCFIT_TRY(dperm.download(perm, (size_t)*total * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
     return PCFIT_OK;
 }

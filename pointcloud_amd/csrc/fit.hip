@@ -842,6 +842,7 @@ using namespace pcfit;
 PCFIT_API int pcfit_kasa_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                    int64_t max_slice_len, double *cxcyr, int32_t *status, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "kasa: n_slices out of range");
     PCFIT_REQUIRE(n_slices == 0 || (x && y && offsets && cxcyr), "kasa: null pointer");
     return launch_kasa(x, y, offsets, n_slices, max_slice_len, cxcyr, status, as_stream(stream));
@@ -852,6 +853,7 @@ PCFIT_API int pcfit_lm_batch_dev(const double *x, const double *y, const int64_t
                                  double lm_lambda0, double tol_update, double tol_cost, double *out, int32_t *iters,
                                  void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "lm: n_slices out of range");
     PCFIT_REQUIRE(n_slices == 0 || (x && y && offsets && init && out), "lm: null pointer");
     PCFIT_REQUIRE(max_iter >= 0, "lm: max_iter negative");
@@ -864,6 +866,7 @@ PCFIT_API int pcfit_fit_batch_dev(const double *x, const double *y, const int64_
                                   double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
                                   int32_t *status, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "fit: n_slices out of range");
     PCFIT_REQUIRE(n_slices == 0 || (x && y && offsets && out), "fit: null pointer");
     PCFIT_REQUIRE(max_iter >= 0, "fit: max_iter negative");
@@ -878,6 +881,7 @@ PCFIT_API int pcfit_fit_residuals_batch_dev(const double *x, const double *y, co
                                             int32_t n_bins, const double *edges, int64_t *hist, double *rmax_rmin,
                                             int64_t *argmax_argmin, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "fit_residuals: n_slices out of range");
     PCFIT_REQUIRE(n_bins >= 0 && n_bins <= 4096, "fit_residuals: n_bins must be 0..4096");
     PCFIT_REQUIRE(n_slices == 0 || (x && y && offsets && out && rmax_rmin && argmax_argmin),
@@ -893,6 +897,7 @@ PCFIT_API int pcfit_fit_residuals_batch_dev(const double *x, const double *y, co
 // tools only: clocks accumulated per phase by thread 0 of every workgroup (16 counters)
 PCFIT_API int pcfit_debug_phase_clocks(int64_t *out16, int reset)
 {
+    PCFIT_ENTER();
     PCFIT_HIP(hipDeviceSynchronize());
     PCFIT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pcfit::g_phase), 16 * sizeof(int64_t)));
     if (reset) {

@@ -555,6 +555,7 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
                                           const int64_t *hull_start, void *workspace, size_t workspace_bytes,
                                           void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "unique_hull: n_slices out of range");
     if (n_slices == 0)
         return PCFIT_OK;

@@ -35,22 +35,34 @@ int bin_check_windows(const double *z_lo, const double *z_hi, int64_t n_slices, 
 
 // kernel launches are asynchronous: this catches bad launch configurations only
 #define PCFIT_LAUNCH_CHECK() PCFIT_HIP(hipGetLastError())
+// First statement of every entry point that touches the device: HIP keeps the last error of the thread
+// until it is read, so a failed call of the application's own would otherwise fail the next launch check.
+#define PCFIT_ENTER() (void)hipGetLastError()
 
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Device buffer that frees itself: the host-pointer entry points own all the
+// Device memory of the host-pointer entry points comes from a per-device cache of blocks (api.hip):
+// fresh device memory costs far more to map and touch for the first time than the kernels that use it
+// run, so blocks are kept between calls (bounded, see pcfit_release_cache).  A block comes back with
+// whatever the last user left in it.
+int pool_get(size_t bytes, void **ptr, size_t *got);
+void pool_put(void *ptr, size_t bytes);
+int pool_release();
+
+// Device buffer that returns itself: the host-pointer entry points own all the
 // device memory they touch for the duration of one call.
 struct DevBuf {
     void *p = nullptr;
     size_t bytes = 0;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) pool_put(p, bytes); }
     int alloc(size_t n)
     {
         if (p && n <= bytes) return PCFIT_OK;          // reuse
-        if (p) { (void)hipFree(p); p = nullptr; }
-        bytes = n;
-        PCFIT_HIP(hipMalloc(&p, n ? n : 8));
-        return PCFIT_OK;
+        if (p) { pool_put(p, bytes); p = nullptr; bytes = 0; }
+        return pool_get(n, &p, &bytes);
     }
     int upload(const void *src, size_t n, hipStream_t st)
     {

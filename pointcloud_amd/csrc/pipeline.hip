@@ -7,6 +7,9 @@
 #include <map>
 #include <vector>
 
+#include <memory>
+#include <new>
+
 #include "pcfit_internal.h"
 
 namespace pcfit {
@@ -33,6 +36,9 @@ __global__ __launch_bounds__(OV_BLOCK) void ovality_kernel(const double *__restr
     if (n < 1 || n > cap || !(cx == cx) || !(cy == cy) || !(R == R)) {
         if (tid < 5)
             scal[5 * s + tid] = qnan;
+        if (dev_uniform)
+            for (int64_t k = tid; k < grid_len; k += OV_BLOCK)
+                dev_uniform[s * grid_len + k] = qnan;
         return;
     }
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -121,6 +127,10 @@ __global__ __launch_bounds__(OV_BLOCK) void ovality_kernel(const double *__restr
         acc[0] += v * cos(ang);
         acc[1] -= v * sin(ang);
     }
+    // the rest of the row (rows are grid_len apart) holds no profile: NaN, whatever the buffer held
+    if (dev_uniform)
+        for (int64_t k = K + tid; k < grid_len; k += OV_BLOCK)
+            dev_uniform[s * grid_len + k] = qnan;
     block_sum<2>(acc, red + 32);
     if (tid == 0) {
         scal[5 * s] = rmax;
@@ -281,6 +291,7 @@ PCFIT_API int pcfit_ovality_batch_dev(const double *x, const double *y, const in
                                       int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
                                       int64_t grid_len, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "ovality: n_slices out of range");
     if (n_slices == 0)
         return PCFIT_OK;
@@ -307,6 +318,7 @@ PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const in
                                       double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull,
                                       int32_t *status, const int64_t *hull_start)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -342,6 +354,7 @@ PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const in
 PCFIT_API int pcfit_ovality_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                   const double *cxcyr, double *scal, double *dev_uniform, int64_t grid_len)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -517,6 +530,7 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
                                  double *cand_y, uint8_t *mask, double *radius, double *theta,
                                  int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -535,6 +549,119 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
                        dev_uniform, grid_len, total, st);
 }
 
+// A scan kept on the device between calls.
+struct pcfit_scan {
+    DevBuf xyz;
+    int64_t n_points = 0;
+    int device = 0;
+};
+
+namespace pcfit {
+
+constexpr int ZR_BLOCK = 256;
+
+// numpy's min / max of the z column: a NaN anywhere makes both NaN.  part: blocks x {min, max, saw NaN}
+__global__ __launch_bounds__(ZR_BLOCK) void z_range_part_kernel(const double *__restrict__ xyz, int64_t n,
+                                                               double *__restrict__ part)
+{
+    __shared__ double red[3 * (ZR_BLOCK / WAVE)];
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double lo = inf, hi = -inf, bad = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)ZR_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * ZR_BLOCK) {
+        const double z = xyz[3 * i + 2];
+        bad = (z == z) ? bad : 1.0;
+        lo = z < lo ? z : lo;
+        hi = z > hi ? z : hi;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ol = __shfl_xor(lo, m, WAVE), oh = __shfl_xor(hi, m, WAVE), ob = __shfl_xor(bad, m, WAVE);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+        bad = ob > bad ? ob : bad;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[3 * (threadIdx.x >> 6)] = lo;
+        red[3 * (threadIdx.x >> 6) + 1] = hi;
+        red[3 * (threadIdx.x >> 6) + 2] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ZR_BLOCK / WAVE; w++) {
+            lo = red[3 * w] < lo ? red[3 * w] : lo;
+            hi = red[3 * w + 1] > hi ? red[3 * w + 1] : hi;
+            bad = red[3 * w + 2] > bad ? red[3 * w + 2] : bad;
+        }
+        part[3 * blockIdx.x] = lo;
+        part[3 * blockIdx.x + 1] = hi;
+        part[3 * blockIdx.x + 2] = bad;
+    }
+}
+
+__global__ __launch_bounds__(64) void z_range_final_kernel(const double *__restrict__ part, int blocks,
+                                                          double *__restrict__ out)
+{
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double lo = inf, hi = -inf, bad = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 64) {
+        lo = part[3 * b] < lo ? part[3 * b] : lo;
+        hi = part[3 * b + 1] > hi ? part[3 * b + 1] : hi;
+        bad = part[3 * b + 2] > bad ? part[3 * b + 2] : bad;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ol = __shfl_xor(lo, m, WAVE), oh = __shfl_xor(hi, m, WAVE), ob = __shfl_xor(bad, m, WAVE);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+        bad = ob > bad ? ob : bad;
+    }
+    if (threadIdx.x == 0) {
+        const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+        out[0] = bad > 0.0 ? qnan : lo;
+        out[1] = bad > 0.0 ? qnan : hi;
+    }
+}
+
+// bin the resident scan into the windows and run the chain on the slices
+static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
+                       double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
+                       double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status,
+                       double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x, double *cand_y,
+                       uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin, double *ov_scal,
+                       double *dev_uniform, int64_t grid_len, int64_t cand_capacity, hipStream_t st)
+{
+    PCFIT_REQUIRE(n_points >= 0 && S >= 1, "scan_hybrid: need n_points >= 0 and n_slices >= 1");
+    PCFIT_REQUIRE(z_lo && z_hi && offsets, "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(cand_capacity >= 0 && (cand_capacity == 0 || (cand_x && cand_y && mask && radius && theta)),
+                  "scan_hybrid: null pointer");
+    PCFIT_REQUIRE(max_trials >= 0, "scan_hybrid: max_trials negative");
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
+    DevBuf dlo, dhi, doff, dbw, dx, dy;
+    PCFIT_TRY(dlo.upload(z_lo, S * 8, st));
+    PCFIT_TRY(dhi.upload(z_hi, S * 8, st));
+    PCFIT_TRY(doff.alloc((S + 1) * 8));
+    const size_t bws = pcfit_bin_workspace_bytes(n_points, S);
+    PCFIT_TRY(dbw.alloc(bws));
+    PCFIT_TRY(pcfit_bin_count_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(),
+                                  dbw.p, bws, st));
+    PCFIT_TRY(doff.download(offsets, (S + 1) * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
+    PCFIT_TRY(dx.alloc((size_t)total * 8));
+    PCFIT_TRY(dy.alloc((size_t)total * 8));
+    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(),
+                                    dx.as<double>(), dy.as<double>(), nullptr, dbw.p, bws, st));
+    return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
+                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, seed, status, fit,
+                       nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,
+                       ov_scal, dev_uniform, grid_len, cand_capacity, st);
+}
+
+}  // namespace pcfit
+
 PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
                                       int64_t n_slices, double inlier_tol, int32_t max_trials,
                                       double min_inliers_frac, const double *r_range, double huber_delta,
@@ -543,43 +670,80 @@ PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const
                                       uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin,
                                       double *ov_scal, double *dev_uniform, int64_t grid_len, int64_t cand_capacity)
 {
-    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "scan_hybrid: need n_points >= 0 and n_slices >= 1");
-    PCFIT_REQUIRE(z_lo && z_hi && offsets && (xyz || n_points == 0), "scan_hybrid: null pointer");
-    PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "scan_hybrid: null pointer");
-    PCFIT_REQUIRE(cand_capacity >= 0 && (cand_capacity == 0 || (cand_x && cand_y && mask && radius && theta)),
-                  "scan_hybrid: null pointer");
-    PCFIT_REQUIRE(max_trials >= 0, "scan_hybrid: max_trials negative");
-    const int64_t S = n_slices;
-    double geom[3];
-    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(n_points >= 0 && (xyz || n_points == 0), "scan_hybrid: null pointer");
     hipStream_t st = nullptr;
-    // the scan goes to the device once; slices are formed and stay there
-    DevBuf dxyz, dlo, dhi, doff, dbw, dx, dy;
+    DevBuf dxyz;                   // the scan goes to the device once; slices are formed and stay there
     PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
-    PCFIT_TRY(dlo.upload(z_lo, S * 8, st));
-    PCFIT_TRY(dhi.upload(z_hi, S * 8, st));
-    PCFIT_TRY(doff.alloc((S + 1) * 8));
-    const size_t bws = pcfit_bin_workspace_bytes(n_points, S);
-    PCFIT_TRY(dbw.alloc(bws));
-    PCFIT_TRY(pcfit_bin_count_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), S, geom,
-                                  doff.as<int64_t>(), dbw.p, bws, st));
-    PCFIT_TRY(doff.download(offsets, (S + 1) * 8, st));
+    return scan_hybrid(dxyz.as<double>(), n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials, min_inliers_frac,
+                       r_range, huber_delta, use_hull, seed, offsets, status, fit, n_unique, cand_offsets, cand_x,
+                       cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len, cand_capacity, st);
+}
+
+PCFIT_API int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan **scan, double *z_min_max)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(scan && n_points >= 0 && (xyz || n_points == 0), "scan_upload: null pointer or negative size");
+    *scan = nullptr;
+    hipStream_t st = nullptr;
+    std::unique_ptr<pcfit_scan> sc(new (std::nothrow) pcfit_scan);
+    PCFIT_REQUIRE(sc != nullptr, "scan_upload: out of host memory");
+    PCFIT_HIP(hipGetDevice(&sc->device));
+    sc->n_points = n_points;
+    PCFIT_TRY(sc->xyz.upload(xyz, (size_t)n_points * 24, st));
+    if (z_min_max) {
+        const double qnan = __builtin_nan("");
+        z_min_max[0] = z_min_max[1] = qnan;
+        if (n_points > 0) {
+            const int blocks = (int)std::min<int64_t>(2048, (n_points + ZR_BLOCK - 1) / ZR_BLOCK);
+            DevBuf part, out;
+            PCFIT_TRY(part.alloc((size_t)blocks * 24));
+            PCFIT_TRY(out.alloc(16));
+            z_range_part_kernel<<<dim3(blocks), dim3(ZR_BLOCK), 0, st>>>(sc->xyz.as<double>(), n_points,
+                                                                         part.as<double>());
+            PCFIT_LAUNCH_CHECK();
+            z_range_final_kernel<<<dim3(1), dim3(64), 0, st>>>(part.as<double>(), blocks, out.as<double>());
+            PCFIT_LAUNCH_CHECK();
+            PCFIT_TRY(out.download(z_min_max, 16, st));
+        }
+    }
     PCFIT_HIP(hipStreamSynchronize(st));
-    int64_t total, max_len;
-    PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
-    PCFIT_TRY(dx.alloc((size_t)total * 8));
-    PCFIT_TRY(dy.alloc((size_t)total * 8));
-    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), S, geom,
-                                    doff.as<int64_t>(), dx.as<double>(), dy.as<double>(), nullptr, dbw.p, bws, st));
-    return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
-                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, seed, status, fit,
-                       nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,
-                       ov_scal, dev_uniform, grid_len, cand_capacity, st);
+    *scan = sc.release();
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_scan_free(pcfit_scan *scan)
+{
+    PCFIT_ENTER();
+    delete scan;
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi,
+                                         int64_t n_slices, double inlier_tol, int32_t max_trials,
+                                         double min_inliers_frac, const double *r_range, double huber_delta,
+                                         int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status,
+                                         double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                                         double *cand_y, uint8_t *mask, double *radius, double *theta,
+                                         int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
+                                         int64_t grid_len, int64_t cand_capacity)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(scan, "scan_hybrid: scan is null");
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    PCFIT_REQUIRE(dev == scan->device, "scan_hybrid: the scan lives on device %d, the current device is %d",
+                  scan->device, dev);
+    return scan_hybrid(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials,
+                       min_inliers_frac, r_range, huber_delta, use_hull, seed, offsets, status, fit, n_unique,
+                       cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len,
+                       cand_capacity, nullptr);
 }
 
 PCFIT_API int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                      double eps, uint8_t *ok)
 {
+    PCFIT_ENTER();
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -600,6 +764,7 @@ PCFIT_API int pcfit_rank_check_batch(const double *x, const double *y, const int
 
 PCFIT_API int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, uint8_t *ok)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_triples >= 0, "circle3: negative count");
     if (n_triples == 0) return PCFIT_OK;
     PCFIT_REQUIRE(triples && out && ok, "circle3: null pointer");

@@ -280,6 +280,7 @@ PCFIT_API int pcfit_ransac_batch_dev(const double *x, const double *y, const int
                                      double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
                                      int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(trials >= 0, "ransac: trials negative");
     const int64_t tiles = (trials + RS_BLOCK - 1) / RS_BLOCK;
     PCFIT_REQUIRE(n_slices >= 0 && n_slices * (tiles > 0 ? tiles : 1) < (1ll << 31),

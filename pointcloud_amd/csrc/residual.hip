@@ -164,6 +164,7 @@ PCFIT_API int pcfit_residuals_batch_dev(const double *x, const double *y, const 
                                         const double *edges, int64_t *hist, double *rmax_rmin,
                                         int64_t *argmax_argmin, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "residuals: n_slices out of range");
     PCFIT_REQUIRE(n_bins >= 0 && n_bins <= 8192, "residuals: n_bins must be 0..8192");
     if (n_slices == 0)
@@ -180,6 +181,7 @@ PCFIT_API int pcfit_residuals_batch_dev(const double *x, const double *y, const 
 PCFIT_API int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                         const double *cxcyr, int32_t bins, int64_t *sel, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "angle_max: n_slices out of range");
     PCFIT_REQUIRE(bins >= 1 && bins <= 8192, "angle_max: bins must be 1..8192");
     if (n_slices == 0)

@@ -542,6 +542,7 @@ PCFIT_API int pcfit_kasa_split_dev(const double *x, const double *y, const int64
                                    int64_t total_points, double *cxcyr, int32_t *status, void *workspace,
                                    size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_TRY(split_common(x, y, offsets, n_slices, total_points, "kasa_split"));
     if (n_slices == 0) return PCFIT_OK;
     PCFIT_REQUIRE(cxcyr, "kasa_split: null pointer");
@@ -555,6 +556,7 @@ PCFIT_API int pcfit_lm_split_dev(const double *x, const double *y, const int64_t
                                  double lm_lambda0, double tol_update, double tol_cost, double *out, int32_t *iters,
                                  void *workspace, size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_TRY(split_common(x, y, offsets, n_slices, total_points, "lm_split"));
     if (n_slices == 0) return PCFIT_OK;
     PCFIT_REQUIRE(init && out, "lm_split: null pointer");
@@ -570,6 +572,7 @@ PCFIT_API int pcfit_fit_split_dev(const double *x, const double *y, const int64_
                                   double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
                                   int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_TRY(split_common(x, y, offsets, n_slices, total_points, "fit_split"));
     if (n_slices == 0) return PCFIT_OK;
     PCFIT_REQUIRE(kasa_out && out && status, "fit_split: kasa_out, out and status are required");
@@ -587,6 +590,7 @@ PCFIT_API int pcfit_residuals_split_dev(const double *x, const double *y, const 
                                         double *rmax_rmin, int64_t *argmax_argmin, void *workspace,
                                         size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_TRY(split_common(x, y, offsets, n_slices, total_points, "residuals_split"));
     PCFIT_REQUIRE(n_bins >= 0 && n_bins <= 8192, "residuals_split: n_bins must be 0..8192");
     if (n_slices == 0) return PCFIT_OK;
@@ -612,6 +616,7 @@ PCFIT_API int pcfit_angle_max_split_dev(const double *x, const double *y, const 
                                         int64_t total_points, const double *cxcyr, int32_t bins, int64_t *sel,
                                         void *workspace, size_t workspace_bytes, void *stream)
 {
+    PCFIT_ENTER();
     PCFIT_TRY(split_common(x, y, offsets, n_slices, total_points, "angle_max_split"));
     PCFIT_REQUIRE(bins >= 1 && bins <= 8192, "angle_max_split: bins must be 1..8192");
     if (n_slices == 0) return PCFIT_OK;

@@ -687,3 +687,32 @@ def test_year_export_files_and_matcher(tmp_path):
     assert np.all(np.diff(rows["theta"].to_numpy()) >= 0)
     assert match_year_slices(bpath, results[3]["z_center"] + 0.5, 2.0) is None
     assert match_year_slices(pd.DataFrame({"z_center": [1.0]}), 1.0, 2.0) is None
+
+
+def test_resident_scan_gives_the_same_analysis():
+    """A DeviceScan (uploaded once) carries numpy's z range and analyses like the array it came from."""
+    from pointcloud_amd import Config, CylinderAnalyzer, DeviceScan
+    from pointcloud_amd.synth import make_cylinder
+    pts = make_cylinder(200_000, 25, seed=31, outlier_frac=0.03)
+    az = CylinderAnalyzer(Config(min_points_per_slice=500))
+    want = az.analyze_with_progress(pts)
+    with DeviceScan(pts) as scan:
+        assert len(scan) == len(pts)
+        assert scan.z_min == pts[:, 2].min() and scan.z_max == pts[:, 2].max()
+        assert np.array_equal(az.calculate_z_centers(scan), az.calculate_z_centers(pts))
+        seen = []
+        got = az.analyze_with_progress(scan, progress_callback=seen.append)
+        again = az.analyze_with_progress(scan)                  # the copy on the device is reusable
+    assert seen[-1] == 100 and seen == sorted(seen)
+    assert len(got) == len(want) == len(again) > 20
+    for a, b, c in zip(want, got, again):
+        assert a == b == c
+    scan.close()                                                 # closing twice is harmless
+    with pytest.raises(F.PcfitError, match="closed"):
+        az.analyze_with_progress(scan)
+    bad = pts.copy()
+    bad[1234, 2] = np.nan
+    with DeviceScan(bad) as scan:
+        assert np.isnan(scan.z_min) and np.isnan(scan.z_max)
+    with pytest.raises(ValueError):
+        CylinderAnalyzer(Config(z_min=1.0, z_max=9.0)).analyze_with_progress(DeviceScan(pts))

@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "pointcloud_amd", "csrc")
 writers = re.compile(r'^\s*(s_cmp|s_bitcmp|s_add|s_sub|s_and|s_or|s_xor|s_lshl|s_lshr|s_ashr|s_min|s_max|s_abs|s_not|s_andn2|s_orn2|s_nand|s_nor|s_xnor|s_bfe|s_addc|s_subb|s_absdiff|s_wqm|s_bcnt|s_ff|s_flbit|s_quadmask)')
 bad = 0
-for f in sys.argv[1:] or ["api", "fit", "ransac", "residual", "bin", "hull", "pipeline"]:
+for f in sys.argv[1:] or ["api", "fit", "split", "ransac", "residual", "bin", "hull", "pipeline"]:
     out = f"/tmp/check_{f}.s"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off",
                     "-fno-fast-math", f"-I{root}/include", f"-I{src}", "--cuda-device-only", "-S",
