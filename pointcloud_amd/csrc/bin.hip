@@ -192,17 +192,46 @@ __global__ void bin_rowscan_kernel(uint32_t *__restrict__ counts, int64_t chunks
 }
 
 // lanes whose key equals this lane's query: ballots over the key bits
-__device__ __forceinline__ uint64_t match_lanes(const uint64_t *bit_ballot, int nbits, uint32_t query)
+// (NBITS is a compile-time constant so that the ballots stay in scalar registers and the loops unroll)
+template <int NBITS>
+__device__ __forceinline__ uint64_t match_lanes(const uint64_t (&bit_ballot)[NBITS], uint32_t query)
 {
     uint64_t m = ~0ull;
-    for (int b = 0; b < nbits; b++)
+#pragma unroll
+    for (int b = 0; b < NBITS; b++)
         m &= ((query >> b) & 1u) ? bit_ballot[b] : ~bit_ballot[b];
     return m;
 }
 
+template <int NBITS>
+__device__ __forceinline__ void key_ballots(uint32_t key, uint64_t (&bit_ballot)[NBITS])
+{
+#pragma unroll
+    for (int b = 0; b < NBITS; b++)
+        bit_ballot[b] = __ballot((key >> b) & 1u);
+}
+
+// The x, y, z of BIN_UNROLL trips of 64 points, all loads issued before any is used.  Lanes past the end
+// read the chunk's last point (a load without a branch) and get NaN for z: no window.
+__device__ __forceinline__ void load_trips(const double *__restrict__ xyz, int64_t sbase, int64_t end, int lane,
+                                           double (&lx)[BIN_UNROLL], double (&ly)[BIN_UNROLL],
+                                           double (&lz)[BIN_UNROLL])
+{
+#pragma unroll
+    for (int u = 0; u < BIN_UNROLL; u++) {
+        const int64_t i = sbase + 64 * u + lane;
+        const int64_t ic = i < end ? i : end - 1;
+        lx[u] = xyz[3 * ic];
+        ly[u] = xyz[3 * ic + 1];
+        const double z = xyz[3 * ic + 2];
+        lz[u] = i < end ? z : __longlong_as_double(0x7ff8000000000000ll);
+    }
+}
+
+template <int NBITS, bool PERM>
 __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restrict__ xyz, int64_t n, int64_t chunk_len,
                                                         const double *__restrict__ z_lo,
-                                                        const double *__restrict__ z_hi, BinGeom g, int nbits,
+                                                        const double *__restrict__ z_hi, BinGeom g,
                                                         const uint32_t *__restrict__ counts,
                                                         const int64_t *__restrict__ segbase,
                                                         const int64_t *__restrict__ offsets,
@@ -221,14 +250,7 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
     for (int64_t sbase = begin; sbase < end; sbase += 64 * BIN_UNROLL) {
         // the loads of BIN_UNROLL trips are issued together; the trips are then placed in order
         double lx[BIN_UNROLL], ly[BIN_UNROLL], lz[BIN_UNROLL];
-#pragma unroll
-        for (int u = 0; u < BIN_UNROLL; u++) {
-            const int64_t i = sbase + 64 * u + lane;
-            const bool in = i < end;
-            lx[u] = in ? xyz[3 * i] : 0.0;
-            ly[u] = in ? xyz[3 * i + 1] : 0.0;
-            lz[u] = in ? xyz[3 * i + 2] : __longlong_as_double(0x7ff8000000000000ll);       // NaN: no window
-        }
+        load_trips(xyz, sbase, end, lane, lx, ly, lz);
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
             if (sbase + 64 * u >= end)
@@ -240,11 +262,10 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
             windows_of(lz[u], g, z_lo, z_hi, k1, has2);
             // key 0 = no window, key k+1 = window k
             const uint32_t key = (uint32_t)(k1 + 1);
-            uint64_t bit_ballot[16];
-            for (int b = 0; b < nbits; b++)
-                bit_ballot[b] = __ballot((key >> b) & 1u);
+            uint64_t bit_ballot[NBITS];
+            key_ballots<NBITS>(key, bit_ballot);
             const uint64_t twice = __ballot(has2);
-            uint64_t same = match_lanes(bit_ballot, nbits, key);
+            uint64_t same = match_lanes<NBITS>(bit_ballot, key);
             if (twice == 0ull) {
                 if (k1 >= 0) {
                     const int rank = __popcll(same & below), cnt = __popcll(same);
@@ -254,12 +275,12 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
                     const int64_t at = offsets[k1] + rel;
                     x_out[at + rank] = px;
                     y_out[at + rank] = py;
-                    if (perm) perm[at + rank] = i;
+                    if (PERM) perm[at + rank] = i;
                 }
             } else {
                 // window k receives lanes with key1 == k and lanes with key1 == k-1 that lie in two windows
-                const uint64_t from_prev = match_lanes(bit_ballot, nbits, key - 1u) & twice;   // key-1 = window k1-1
-                const uint64_t to_next = match_lanes(bit_ballot, nbits, key + 1u);            // lanes in window k1+1
+                const uint64_t from_prev = match_lanes<NBITS>(bit_ballot, key - 1u) & twice;   // key-1 = window k1-1
+                const uint64_t to_next = match_lanes<NBITS>(bit_ballot, key + 1u);            // lanes in window k1+1
                 int64_t at1 = 0, at2 = 0;
                 int rank1 = 0, cnt1 = 0, rank2 = 0, cnt2 = 0;
                 if (k1 >= 0) {
@@ -285,16 +306,28 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
                         at2 += offsets[k1 + 1];
                     x_out[at1 + rank1] = px;
                     y_out[at1 + rank1] = py;
-                    if (perm) perm[at1 + rank1] = i;
+                    if (PERM) perm[at1 + rank1] = i;
                     if (has2) {
                         x_out[at2 + rank2] = px;
                         y_out[at2 + rank2] = py;
-                        if (perm) perm[at2 + rank2] = i;
+                        if (PERM) perm[at2 + rank2] = i;
                     }
                 }
             }
         }
     }
+}
+
+// the kernels take the number of key bits as a template argument: the next size up of a few
+template <int N> struct KeyBits { static constexpr int value = N; };
+template <class F> static void with_key_bits(int nbits, F &&f)
+{
+    if (nbits <= 3) f(KeyBits<3>{});
+    else if (nbits <= 6) f(KeyBits<6>{});
+    else if (nbits <= 8) f(KeyBits<8>{});
+    else if (nbits <= 10) f(KeyBits<10>{});
+    else if (nbits <= 12) f(KeyBits<12>{});
+    else f(KeyBits<15>{});
 }
 
 struct BinPlan {
@@ -427,8 +460,15 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     int nbits = 1;
     while ((1ll << nbits) < n_slices + 2)
         nbits++;
-    bin_scatter_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
-        xyz, n_points, p.chunk_len, z_lo, z_hi, g, nbits, counts, segsum, offsets, x_out, y_out, perm);
+    with_key_bits(nbits, [&](auto tag) {
+        constexpr int NB = decltype(tag)::value;
+        if (perm)
+            bin_scatter_kernel<NB, true><<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
+                xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+        else
+            bin_scatter_kernel<NB, false><<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
+                xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+    });
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }

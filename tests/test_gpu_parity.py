@@ -218,6 +218,15 @@ def test_bin_slices_stable_and_exact():
     assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
     off, x, y, perm = F.bin_slices(pts, [10.0], [10.0])            # zero-width window
     assert np.array_equal(perm, np.nonzero(pts[:, 2] == 10.0)[0])
+    # windows that share edges, z on a coarse grid: most points lie on an edge and belong to two windows
+    q = pts[:120_000].copy()
+    q[:, 2] = np.round(q[:, 2] * 2.0) / 2.0
+    zc, lo, hi = R.slice_windows(0.0, 114.0, 0.5)
+    off, x, y, perm = F.bin_slices(q, lo, hi)
+    o_ref, p_ref = N.bin_slices(q, lo, hi)
+    assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
+    assert off[-1] > 1.5 * np.count_nonzero((q[:, 2] >= lo[0]) & (q[:, 2] <= hi[-1]))
+    assert np.array_equal(x, q[perm, 0]) and np.array_equal(y, q[perm, 1])
 
 
 def test_degenerate_slices():

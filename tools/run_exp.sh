@@ -1,9 +1,7 @@
 # scratch driver for timing experiments on the GPU box
 set -e
 cd $GRAFT_REPO_ROOT
-for S in 57 2000; do
-  for CH in 2048 8192 32768; do
-    echo "== S=$S chunks=$CH"
-    C4N=50000000 C4S=$S PCFIT_BIN_CHUNKS=$CH timeout -k 10 120 python3 -u tools/exp_all.py c4 2>&1 | grep -E "bin count|bin scatter"
-  done
+for S in 57 200 2000; do
+    echo "== S=$S"
+    C4N=50000000 C4S=$S timeout -k 10 120 python3 -u tools/exp_all.py c4 2>&1 | grep -E "bin count|bin scatter"
 done
