@@ -3,12 +3,16 @@
 // that chains unique -> hull -> RANSAC -> Kasa -> LM -> metrics for a batch of
 // slices (fit_circle_hybrid_at_z, circle_fitting.py:146-232, followed by the
 // per-slice metrics of analyzer.py:83-95).
+#include <string.h>
+
 #include <algorithm>
 #include <map>
-#include <vector>
-
 #include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <tuple>
+#include <vector>
 
 #include "pcfit_internal.h"
 
@@ -375,6 +379,84 @@ PCFIT_API int pcfit_ovality_batch(const double *x, const double *y, const int64_
     return PCFIT_OK;
 }
 
+// Sampling tables for the candidate counts in `sizes` (each trials x 3), one after the other in `out`.
+// A table depends on the seed state, the count and the number of trials only (every slice's RANSAC starts
+// its own default_rng(seed), circle_fitting.py:124), and drawing one is a serial walk of the generator:
+// tables are kept between calls (a bounded, mutex-guarded cache) and the missing ones are drawn by
+// several host threads at once.
+namespace {
+struct TableKey {
+    uint64_t st[4];
+    int64_t n;
+    int32_t trials;
+    bool operator<(const TableKey &o) const
+    {
+        return std::tie(st[0], st[1], st[2], st[3], n, trials) < std::tie(o.st[0], o.st[1], o.st[2], o.st[3], o.n, o.trials);
+    }
+};
+std::mutex g_tab_mu;
+std::map<TableKey, std::shared_ptr<const std::vector<int32_t>>> g_tab;
+size_t g_tab_bytes = 0;
+constexpr size_t TAB_CACHE_BYTES = (size_t)256 << 20;
+}  // namespace
+
+static int sampling_tables(const uint64_t state[4], const std::vector<int64_t> &sizes, int32_t trials,
+                           std::vector<int32_t> &out)
+{
+    const size_t K = sizes.size(), per = (size_t)trials * 3;
+    std::vector<std::shared_ptr<const std::vector<int32_t>>> tab(K);
+    std::vector<size_t> missing;
+    {
+        std::lock_guard<std::mutex> lock(g_tab_mu);
+        for (size_t k = 0; k < K; k++) {
+            const TableKey key{{state[0], state[1], state[2], state[3]}, sizes[k], trials};
+            auto it = g_tab.find(key);
+            if (it != g_tab.end())
+                tab[k] = it->second;
+            else
+                missing.push_back(k);
+        }
+    }
+    if (!missing.empty()) {
+        std::vector<int> rc(missing.size(), PCFIT_OK);
+        std::vector<std::shared_ptr<std::vector<int32_t>>> fresh(missing.size());
+        const int T = (int)std::min<size_t>(missing.size(), std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+        auto work = [&](int t) {
+            for (size_t j = t; j < missing.size(); j += T) {
+                fresh[j] = std::make_shared<std::vector<int32_t>>(per);
+                rc[j] = pcfit_choice3_table(state, sizes[missing[j]], trials, fresh[j]->data());
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < T; t++)
+            pool.emplace_back(work, t);
+        work(0);
+        for (auto &th : pool)
+            th.join();
+        for (int r : rc)
+            if (r != PCFIT_OK)
+                return r;                   // (the message was set by the thread that failed; report the code)
+        std::lock_guard<std::mutex> lock(g_tab_mu);
+        if (g_tab_bytes + missing.size() * per * 4 > TAB_CACHE_BYTES) {
+            g_tab.clear();
+            g_tab_bytes = 0;
+        }
+        for (size_t j = 0; j < missing.size(); j++) {
+            tab[missing[j]] = fresh[j];
+            if (per * 4 <= TAB_CACHE_BYTES / 4) {
+                const TableKey key{{state[0], state[1], state[2], state[3]}, sizes[missing[j]], trials};
+                if (g_tab.emplace(key, fresh[j]).second)
+                    g_tab_bytes += per * 4;
+            }
+        }
+    }
+    out.resize(K * per);
+    for (size_t k = 0; k < K; k++)
+        if (per)
+            memcpy(out.data() + k * per, tab[k]->data(), per * 4);
+    return PCFIT_OK;
+}
+
 // The chain on slices that are already on the device (dxp, dyp, doffp; offsets = the same CSR offsets on
 // the host).  ux / uy may be null (then the distinct points stay on the device); the candidate arrays hold
 // cand_capacity entries.
@@ -439,18 +521,20 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     uint64_t state[4];
     PCFIT_TRY(pcfit_seed_state(seed, state));
     std::map<int64_t, int32_t> table_id;
-    std::vector<int32_t> of_slice(S, 0), tables;
+    std::vector<int32_t> of_slice(S, 0);
+    std::vector<int64_t> sizes;
     for (int64_t s = 0; s < S; s++) {
         const int64_t m = cand_offsets[s + 1] - cand_offsets[s];
         if (m < 3) continue;
         auto it = table_id.find(m);
         if (it == table_id.end()) {
             it = table_id.emplace(m, (int32_t)table_id.size()).first;
-            tables.resize(tables.size() + (size_t)max_trials * 3);
-            PCFIT_TRY(pcfit_choice3_table(state, m, max_trials, tables.data() + (size_t)it->second * max_trials * 3));
+            sizes.push_back(m);
         }
         of_slice[s] = it->second;
     }
+    std::vector<int32_t> tables;
+    PCFIT_TRY(sampling_tables(state, sizes, max_trials, tables));
     DevBuf dtab, dof, dmodel, dscore, dbest, dmask, drst, drws;
     PCFIT_TRY(dtab.upload(tables.data(), tables.size() * 4, st));
     PCFIT_TRY(dof.upload(of_slice.data(), S * 4, st));
