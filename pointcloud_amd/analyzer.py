@@ -163,17 +163,62 @@ class CylinderAnalyzer:
         h = _ffi.scan_hybrid_batch(points, z_centers - dz, z_centers + dz, _FIT["inlier_tol"], _FIT["max_trials"],
                                    _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"])
         counts = np.diff(h["offsets"])
+        # the columns of all result dicts at once (reference: analyzer.py:77-127 builds them slice by slice);
+        # per window only the dict itself is put together
+        co = h["cand_offsets"]
+        good = np.flatnonzero((counts >= self.config.min_points_per_slice) & (h["status"] == 0))
+        at = {int(s): j for j, s in enumerate(good)}
+        cand_x, cand_y = h["cand_x"], h["cand_y"]
+        i_max, i_min = co[good] + h["argmax"][good], co[good] + h["argmin"][good]
+        x_max, y_max = cand_x[i_max].tolist(), cand_y[i_max].tolist()
+        x_min, y_min = cand_x[i_min].tolist(), cand_y[i_min].tolist()
+        fit = h["fit"].tolist()
+        ov = [list(h["ov"][:, k]) for k in range(5)]
+        pairs = np.stack([cand_x, cand_y], axis=1).tolist()
+        z_low, z_high = list(z_centers - dz), list(z_centers + dz)
+        n_kept = np.minimum(counts, self.config.max_points_for_speed).tolist()
+        co = co.tolist()
         for s, zc in enumerate(z_centers):
-            n0 = int(counts[s])
-            if n0 < self.config.min_points_per_slice:
-                yield None, None, f"SKIP zc={zc:.3f}: too sparse ({n0} points)"
+            j = at.get(s)
+            if j is None:
+                n0 = int(counts[s])
+                if n0 < self.config.min_points_per_slice:
+                    yield None, None, f"SKIP zc={zc:.3f}: too sparse ({n0} points)"
+                else:
+                    yield None, None, f"SKIP zc={zc:.3f}: hybrid fit failed"
                 continue
-            if h["status"][s] != 0:
-                yield None, None, f"SKIP zc={zc:.3f}: hybrid fit failed"
-                continue
-            n0 = min(n0, self.config.max_points_for_speed)
-            result, _, _, _, edge = self._slice_result(s, zc, n0, h, want_ov=False)
-            yield result, (edge if want_edges else None), None
+            c0, c1 = co[s], co[s + 1]
+            cx, cy, R = fit[s]
+            result = {
+                "z_center": zc,
+                "z_low": z_low[s],
+                "z_high": z_high[s],
+                "n_points_slice": n_kept[s],
+                "n_edge": c1 - c0,
+                "cx": cx, "cy": cy, "R": R,
+                "Rmax": ov[0][s],
+                "Rmin": ov[1][s],
+                "x_at_Rmax": x_max[j],
+                "y_at_Rmax": y_max[j],
+                "x_at_Rmin": x_min[j],
+                "y_at_Rmin": y_min[j],
+                "ovality_abs": ov[2][s],
+                "ovality_pct": ov[3][s],
+                "k2_amp": ov[4][s],
+                "cost": 0.0,
+                "boundary_points": pairs[c0:c1],
+            }
+            edge = None
+            if want_edges:
+                edge = {
+                    "z_center": zc,
+                    "x": cand_x[c0:c1],
+                    "y": cand_y[c0:c1],
+                    "radius": h["radius"][c0:c1],
+                    "theta": h["theta"][c0:c1],
+                    "inlier": h["mask"][c0:c1].astype(int),
+                }
+            yield result, edge, None
 
     def analyze_with_progress(self, points: np.ndarray, progress_callback=None):
         """Analyze points with progress reporting (reference: analyzer.py:181-230).
