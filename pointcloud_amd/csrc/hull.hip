@@ -21,11 +21,13 @@
 // (16 B of coordinates + 2 B of index per point); longer slices run the same
 // code on a global-memory workspace - after a filter that drops the points
 // which cannot be hull vertices: around the slice's centroid c the plane is cut
-// into K sectors (128..512 by slice length), m = the smallest of the per-sector
-// largest distances from c, and every point closer to c than m cos(8/K) lies
-// strictly inside the convex hull of the sector maxima (two neighbours among
-// them are at most 16/K rad apart as seen from c, so the chord between them
-// stays outside that disc).
+// into K sectors (128..512 by slice length) and the farthest point of every
+// sector is found.  A point of sector j lies between the farthest points A, B
+// of the two flanking sectors as seen from c, at most 24/K rad apart, and the
+// segment AB stays farther from c than min(|cA|, |cB|) cos(12/K): a point closer
+// than that is inside the triangle cAB, hence no hull vertex (details at
+// hull_filter_slice_kernel).  The threshold follows the outline sector by
+// sector, so it does not matter where inside the outline the centroid lies.
 // For a noisy ring that leaves a few percent of the points.  The filter runs
 // one workgroup per 8192 points; what it keeps is then sorted, made unique and
 // hulled as before, so hull vertices and their order are unchanged, while
@@ -177,11 +179,12 @@ constexpr int HULL_SECTORS = 512;
 constexpr int64_t HULL_FILTER_MAX_SLICES = 4096;       // (the per-slice sector table is 4 KB)
 
 struct HullSliceAux {
-    double cx, cy, thr;                 // centroid; squared distance below which a point is dropped
+    double cx, cy, spare;               // centroid
     long long filtered;                 // 1: the slice went through the filter, kept points are in the workspace
     unsigned long long kept;            // how many
     long long sectors;                  // sectors in use: fewer for shorter slices, so that each still holds a crowd
-    unsigned long long sect[HULL_SECTORS];      // bit pattern + 1 of the largest squared distance per sector
+    unsigned long long sect[HULL_SECTORS];      // bit pattern + 1 of the largest squared distance per sector; after
+                                                // the second per-slice step: bit pattern of the sector's threshold
 };
 
 // sector of a direction: uniform in the "diamond angle" dy / (|dx| + |dy|), whose slope against the
@@ -244,11 +247,16 @@ __global__ __launch_bounds__(SPLIT_BLOCK) void hull_filter_kernel(const double *
             if (lsect[j])
                 atomicMax(&aux[r.slice].sect[j], lsect[j]);
     } else {
-        const double cx = aux[r.slice].cx, cy = aux[r.slice].cy, thr = aux[r.slice].thr;
+        const double cx = aux[r.slice].cx, cy = aux[r.slice].cy;
+        const int K = (int)aux[r.slice].sectors;
+        for (int j = threadIdx.x; j < K; j += SPLIT_BLOCK)
+            lsect[j] = aux[r.slice].sect[j];                    // by now: the sector's threshold (bits of a double)
+        __syncthreads();
         const int lane = threadIdx.x & 63;
         segment_points(r, [&](double px, double py, int32_t, bool valid) {
             const double dx = px - cx, dy = py - cy;
             const double r2 = dx * dx + dy * dy;
+            const double thr = __longlong_as_double((long long)lsect[sector_of(dx, dy, K)]);
             const bool keep = valid && !(r2 < thr);            // (a NaN stays)
             const unsigned long long m = __ballot(keep);
             if (m) {
@@ -311,15 +319,34 @@ __global__ __launch_bounds__(WAVE) void hull_filter_slice_kernel(const int64_t *
             const unsigned long long o = __shfl_xor(m, k, WAVE);
             m = o < m ? o : m;
         }
-        if (threadIdx.x == 0) {
-            // an empty sector (or a centroid that is not finite): nothing can be dropped
-            double thr = 0.0;
-            if (m != 0ull && a.cx == a.cx && a.cy == a.cy) {
-                const double m2 = __longlong_as_double((long long)(m - 1ull));
-                const double c = cos(8.0 / (double)K);
-                thr = m2 * (c * c) * (1.0 - 1e-9);
+        // Every sector holds a point (else, or with a centroid that is not finite, nothing is dropped): the
+        // hull then contains a disc about the centroid O.  For a point P of sector j take the farthest points
+        // A, B of the two flanking sectors: P's direction lies between theirs, the angle AOB is at most three
+        // sector widths (24 / K), and the segment AB stays farther from O than min(|OA|, |OB|) cos(12 / K).
+        // A point of sector j closer than that lies inside the triangle OAB, so it is no hull vertex.  The
+        // thresholds follow the outline sector by sector, so a centroid that outliers have pulled off the
+        // centre costs nothing.  They replace the table in place (reads of the whole wave first, then writes).
+        const bool live = m != 0ull && a.cx == a.cx && a.cy == a.cy;
+        const double c = cos(12.0 / (double)K);
+        const double shrink = (c * c) * (1.0 - 1e-9);
+        constexpr int PER = HULL_SECTORS / WAVE;
+        double thr[PER];
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int j = threadIdx.x + t * WAVE;
+            thr[t] = 0.0;
+            if (j < K && live) {
+                const unsigned long long p = a.sect[(j + K - 1) % K], q = a.sect[(j + 1) % K];
+                const unsigned long long lo = p < q ? p : q;
+                thr[t] = __longlong_as_double((long long)(lo - 1ull)) * shrink;
             }
-            a.thr = thr;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < PER; t++) {
+            const int j = threadIdx.x + t * WAVE;
+            if (j < K)
+                a.sect[j] = (unsigned long long)__double_as_longlong(thr[t]);
         }
     }
 }
@@ -374,23 +401,27 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
     __syncthreads();
 
-    // ---- sort (ascending-only bitonic network, virtual +inf padding)
-    int64_t P = 1;
-    while (P < n) P <<= 1;
-    for (int64_t k = 2; k <= P; k <<= 1) {
-        for (int64_t d = k >> 1; d >= 1; d >>= 1) {
-            const bool flip = d == (k >> 1);
-            for (int64_t q = tid; q < (P >> 1); q += HULL_BLOCK) {
-                int64_t i, j;
+    // ---- sort (ascending-only bitonic network, virtual +inf padding).  Strides are powers of two: the
+    // partner indices come from shifts and masks on 32-bit values (n < 2^31).
+    const uint32_t n32 = (uint32_t)n;
+    int lp = 0;
+    while ((1u << lp) < n32 && lp < 31) lp++;
+    const uint32_t half = lp > 0 ? (1u << (lp - 1)) : 0u;
+    for (int lk = 1; lk <= lp; lk++) {
+        for (int ld = lk - 1; ld >= 0; ld--) {
+            const uint32_t d = 1u << ld;
+            const bool flip = ld == lk - 1;
+            for (uint32_t q = tid; q < half; q += HULL_BLOCK) {
+                const uint32_t blk = q >> ld, o = q & (d - 1u);
+                uint32_t i, j;
                 if (flip) {
-                    const int64_t blk = q / d, o = q % d;
-                    i = blk * k + o;
-                    j = blk * k + (k - 1 - o);
+                    i = (blk << lk) + o;
+                    j = (blk << lk) + ((1u << lk) - 1u - o);
                 } else {
-                    i = 2 * d * (q / d) + (q % d);
+                    i = (blk << (ld + 1)) + o;
                     j = i + d;
                 }
-                if (j < n) {
+                if (j < n32) {
                     const double ax = px[i], ay = py[i], bx = px[j], by = py[j];
                     if (lex_less(bx, by, ax, ay)) {
                         px[i] = bx; py[i] = by;
