@@ -468,25 +468,32 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
                        double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
                        int64_t cand_capacity, hipStream_t st)
 {
+    // Small per-slice arrays travel packed, one copy per stage and direction: every copy from or to
+    // pageable memory is a blocking call of some tens of microseconds, more than the kernels of a small scan.
+    auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    std::vector<char> hbuf;
+
     // 1. distinct points, rank check, hull
-    DevBuf dux, duy, dnu, dhi, dnh, dst, dhs, dws;
+    DevBuf dux, duy, dhi, dhs, dws, d1;
     PCFIT_TRY(dux.alloc(total * 8));
     PCFIT_TRY(duy.alloc(total * 8));
-    PCFIT_TRY(dnu.alloc(S * 8));
     PCFIT_TRY(dhi.alloc(total * 8));
-    PCFIT_TRY(dnh.alloc(S * 8));
-    PCFIT_TRY(dst.alloc(S * 4));
+    const size_t nu_at = 0, nh_at = (size_t)S * 8, st1_at = (size_t)S * 16, d1_bytes = (size_t)S * 20;
+    PCFIT_TRY(d1.alloc(d1_bytes));                     // n_unique | n_hull | status
+    int64_t *dnu = reinterpret_cast<int64_t *>(d1.as<char>() + nu_at);
+    int64_t *dnh = reinterpret_cast<int64_t *>(d1.as<char>() + nh_at);
+    int32_t *dst1 = reinterpret_cast<int32_t *>(d1.as<char>() + st1_at);
     if (hull_start) PCFIT_TRY(dhs.upload(hull_start, S * 8, st));
     PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, S)));
-    PCFIT_TRY(pcfit_unique_hull_batch_dev(dxp, dyp, doffp, S, max_len,
-                                          dux.as<double>(), duy.as<double>(), dnu.as<int64_t>(), dhi.as<int64_t>(),
-                                          dnh.as<int64_t>(), dst.as<int32_t>(), dhs.as<int64_t>(), dws.p, dws.bytes,
-                                          st));
-    std::vector<int64_t> n_hull(S);
-    PCFIT_TRY(dnu.download(n_unique, S * 8, st));
-    PCFIT_TRY(dnh.download(n_hull.data(), S * 8, st));
-    PCFIT_TRY(dst.download(status, S * 4, st));
+    PCFIT_TRY(pcfit_unique_hull_batch_dev(dxp, dyp, doffp, S, max_len, dux.as<double>(), duy.as<double>(), dnu,
+                                          dhi.as<int64_t>(), dnh, dst1, dhs.as<int64_t>(), dws.p, dws.bytes, st));
+    hbuf.resize(d1_bytes);
+    PCFIT_TRY(d1.download(hbuf.data(), d1_bytes, st));
     PCFIT_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> n_hull(S);
+    memcpy(n_unique, hbuf.data() + nu_at, (size_t)S * 8);
+    memcpy(n_hull.data(), hbuf.data() + nh_at, (size_t)S * 8);
+    memcpy(status, hbuf.data() + st1_at, (size_t)S * 4);
 
     // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
     int64_t max_cand = 0;
@@ -505,17 +512,6 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
                   (long long)n_cand);
         return PCFIT_ERR_INVALID;
     }
-    PCFIT_TRY(dst.upload(status, S * 4, st));
-    DevBuf dco, dcx, dcy;
-    PCFIT_TRY(dco.upload(cand_offsets, (S + 1) * 8, st));
-    PCFIT_TRY(dcx.alloc(n_cand * 8));
-    PCFIT_TRY(dcy.alloc(n_cand * 8));
-    gather_candidates_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dux.as<double>(), duy.as<double>(),
-                                                                     doffp, dhi.as<int64_t>(),
-                                                                     dco.as<int64_t>(), use_hull ? 1 : 0,
-                                                                     dcx.as<double>(), dcy.as<double>(),
-                                                                     dst.as<int32_t>());
-    PCFIT_LAUNCH_CHECK();
 
     // 3. RANSAC on the candidates: one sampling table per distinct candidate count
     uint64_t state[4];
@@ -535,24 +531,49 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     }
     std::vector<int32_t> tables;
     PCFIT_TRY(sampling_tables(state, sizes, max_trials, tables));
-    DevBuf dtab, dof, dmodel, dscore, dbest, dmask, drst, drws;
+    // up: cand_offsets | status | table of slice
+    DevBuf d2;
+    const size_t co_at = 0, st2_at = (size_t)(S + 1) * 8, of_at = st2_at + (size_t)S * 4, d2_bytes = of_at + (size_t)S * 4;
+    hbuf.resize(d2_bytes);
+    memcpy(hbuf.data() + co_at, cand_offsets, (size_t)(S + 1) * 8);
+    memcpy(hbuf.data() + st2_at, status, (size_t)S * 4);
+    memcpy(hbuf.data() + of_at, of_slice.data(), (size_t)S * 4);
+    PCFIT_TRY(d2.upload(hbuf.data(), d2_bytes, st));
+    const int64_t *dco = reinterpret_cast<const int64_t *>(d2.as<char>() + co_at);
+    int32_t *dst = reinterpret_cast<int32_t *>(d2.as<char>() + st2_at);
+    const int32_t *dof = reinterpret_cast<const int32_t *>(d2.as<char>() + of_at);
+    // everything that goes back at the end lives in one block:
+    // fit | argmax_argmin | ov | cand_x | cand_y | radius | theta | mask
+    DevBuf dout;
+    const size_t C8 = (size_t)n_cand * 8;
+    const size_t fit_at = 0, am_at = (size_t)S * 24, ov_at = am_at + (size_t)S * 16, cx_at = ov_at + (size_t)S * 40,
+                 cy_at = cx_at + C8, rad_at = cy_at + C8, th_at = rad_at + C8, mask_at = th_at + C8,
+                 out_bytes = up8(mask_at + (size_t)n_cand);
+    PCFIT_TRY(dout.alloc(out_bytes));
+    char *ob = dout.as<char>();
+    double *dfit = reinterpret_cast<double *>(ob + fit_at), *dov = reinterpret_cast<double *>(ob + ov_at);
+    int64_t *dam = reinterpret_cast<int64_t *>(ob + am_at);
+    double *dcx = reinterpret_cast<double *>(ob + cx_at), *dcy = reinterpret_cast<double *>(ob + cy_at);
+    double *drad = reinterpret_cast<double *>(ob + rad_at), *dth = reinterpret_cast<double *>(ob + th_at);
+    uint8_t *dmask = reinterpret_cast<uint8_t *>(ob + mask_at);
+    gather_candidates_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dux.as<double>(), duy.as<double>(), doffp,
+                                                                     dhi.as<int64_t>(), dco, use_hull ? 1 : 0, dcx, dcy,
+                                                                     dst);
+    PCFIT_LAUNCH_CHECK();
+    DevBuf dtab, dmodel, d3, drws;
     PCFIT_TRY(dtab.upload(tables.data(), tables.size() * 4, st));
-    PCFIT_TRY(dof.upload(of_slice.data(), S * 4, st));
     PCFIT_TRY(dmodel.alloc(S * 24));
-    PCFIT_TRY(dscore.alloc(S * 4));
-    PCFIT_TRY(dbest.alloc(S * 4));
-    PCFIT_TRY(dmask.alloc(n_cand));
-    PCFIT_TRY(drst.alloc(S * 4));
+    PCFIT_TRY(d3.alloc((size_t)S * 12));               // score | ransac status | best trial
+    int32_t *dscore = d3.as<int32_t>(), *drst = dscore + S, *dbest = drst + S;
     PCFIT_TRY(drws.alloc(pcfit_ransac_workspace_bytes(S)));
-    PCFIT_TRY(pcfit_ransac_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, inlier_tol, max_trials,
-                                     min_inliers_frac, r_range, dtab.as<int32_t>(), dof.as<int32_t>(),
-                                     dmodel.as<double>(), dscore.as<int32_t>(), dbest.as<int32_t>(),
-                                     dmask.as<uint8_t>(), drst.as<int32_t>(), drws.p, drws.bytes, st));
-    std::vector<int32_t> score(S), rst(S), st2(S);
-    PCFIT_TRY(dscore.download(score.data(), S * 4, st));
-    PCFIT_TRY(drst.download(rst.data(), S * 4, st));
-    PCFIT_TRY(dst.download(st2.data(), S * 4, st));
+    PCFIT_TRY(pcfit_ransac_batch_dev(dcx, dcy, dco, S, inlier_tol, max_trials, min_inliers_frac, r_range,
+                                     dtab.as<int32_t>(), dof, dmodel.as<double>(), dscore, dbest, dmask, drst, drws.p,
+                                     drws.bytes, st));
+    std::vector<int32_t> back((size_t)S * 3);          // score | ransac status | status after the gather
+    PCFIT_TRY(d3.download(back.data(), (size_t)S * 8, st));
+    PCFIT_HIP(hipMemcpyAsync(back.data() + 2 * S, dst, (size_t)S * 4, hipMemcpyDeviceToHost, st));
     PCFIT_HIP(hipStreamSynchronize(st));
+    const int32_t *score = back.data(), *rst = score + S, *st2 = rst + S;
 
     // 4. inliers -> Kasa start -> LM (circle_fitting.py:215-222)
     std::vector<int64_t> inl_off(S + 1, 0);
@@ -564,45 +585,56 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
         inl_off[s + 1] = inl_off[s] + k;
         max_inl = std::max(max_inl, k);
     }
-    DevBuf dio, dix, diy, dfit;
+    DevBuf dio, dix, diy;
     PCFIT_TRY(dio.upload(inl_off.data(), (S + 1) * 8, st));
     PCFIT_TRY(dix.alloc(inl_off[S] * 8));
     PCFIT_TRY(diy.alloc(inl_off[S] * 8));
-    PCFIT_TRY(dfit.alloc(S * 24));
-    compact_inliers_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dcx.as<double>(), dcy.as<double>(),
-                                                                   dco.as<int64_t>(), dmask.as<uint8_t>(),
-                                                                   dio.as<int64_t>(), dix.as<double>(),
-                                                                   diy.as<double>());
+    compact_inliers_kernel<<<dim3((unsigned)S), dim3(256), 0, st>>>(dcx, dcy, dco, dmask, dio.as<int64_t>(),
+                                                                   dix.as<double>(), diy.as<double>());
     PCFIT_LAUNCH_CHECK();
     PCFIT_TRY(pcfit_fit_batch_dev(dix.as<double>(), diy.as<double>(), dio.as<int64_t>(), S, max_inl, huber_delta, 100,
-                                  1e-2, 1e-10, 1e-12, nullptr, dfit.as<double>(), nullptr, nullptr, st));
+                                  1e-2, 1e-10, 1e-12, nullptr, dfit, nullptr, nullptr, st));
 
     // 5. metrics on the candidates about the fitted circle (analyzer.py:83-95)
-    DevBuf dth, drad, drm, dam, dov, ddev;
-    PCFIT_TRY(dth.alloc(n_cand * 8));
-    PCFIT_TRY(drad.alloc(n_cand * 8));
+    DevBuf drm, ddev;
     PCFIT_TRY(drm.alloc(S * 16));
-    PCFIT_TRY(dam.alloc(S * 16));
-    PCFIT_TRY(dov.alloc(S * 40));
     if (dev_uniform) PCFIT_TRY(ddev.alloc((size_t)S * grid_len * 8));
-    PCFIT_TRY(pcfit_residuals_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, dfit.as<double>(),
-                                        dth.as<double>(), nullptr, drad.as<double>(), 0, nullptr, nullptr,
-                                        drm.as<double>(), dam.as<int64_t>(), st));
-    PCFIT_TRY(pcfit_ovality_batch_dev(dcx.as<double>(), dcy.as<double>(), dco.as<int64_t>(), S, max_cand,
-                                      dfit.as<double>(), dov.as<double>(), ddev.as<double>(), grid_len, st));
+    PCFIT_TRY(pcfit_residuals_batch_dev(dcx, dcy, dco, S, dfit, dth, nullptr, drad, 0, nullptr, nullptr,
+                                        drm.as<double>(), dam, st));
+    PCFIT_TRY(pcfit_ovality_batch_dev(dcx, dcy, dco, S, max_cand, dfit, dov, ddev.as<double>(), grid_len, st));
 
-    PCFIT_TRY(dfit.download(fit, S * 24, st));
+    // (with very many candidates - all distinct points of long slices - the sections go out one by one
+    // instead: a staging copy of that size would cost more than the calls it saves)
+    const bool packed = out_bytes <= ((size_t)8 << 20);
+    if (packed) {
+        hbuf.resize(out_bytes);
+        PCFIT_TRY(dout.download(hbuf.data(), out_bytes, st));
+    } else {
+        PCFIT_HIP(hipMemcpyAsync(fit, dfit, (size_t)S * 24, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(argmax_argmin, dam, (size_t)S * 16, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(ov_scal, dov, (size_t)S * 40, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(cand_x, dcx, C8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(cand_y, dcy, C8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(radius, drad, C8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(theta, dth, C8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipMemcpyAsync(mask, dmask, (size_t)n_cand, hipMemcpyDeviceToHost, st));
+    }
     if (ux) PCFIT_TRY(dux.download(ux, total * 8, st));
     if (uy) PCFIT_TRY(duy.download(uy, total * 8, st));
-    PCFIT_TRY(dcx.download(cand_x, n_cand * 8, st));
-    PCFIT_TRY(dcy.download(cand_y, n_cand * 8, st));
-    PCFIT_TRY(dmask.download(mask, n_cand, st));
-    PCFIT_TRY(drad.download(radius, n_cand * 8, st));
-    PCFIT_TRY(dth.download(theta, n_cand * 8, st));
-    PCFIT_TRY(dam.download(argmax_argmin, S * 16, st));
-    PCFIT_TRY(dov.download(ov_scal, S * 40, st));
     if (dev_uniform) PCFIT_TRY(ddev.download(dev_uniform, (size_t)S * grid_len * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
+    if (packed) {
+        memcpy(fit, hbuf.data() + fit_at, (size_t)S * 24);
+        memcpy(argmax_argmin, hbuf.data() + am_at, (size_t)S * 16);
+        memcpy(ov_scal, hbuf.data() + ov_at, (size_t)S * 40);
+        if (n_cand) {
+            memcpy(cand_x, hbuf.data() + cx_at, C8);
+            memcpy(cand_y, hbuf.data() + cy_at, C8);
+            memcpy(radius, hbuf.data() + rad_at, C8);
+            memcpy(theta, hbuf.data() + th_at, C8);
+            memcpy(mask, hbuf.data() + mask_at, (size_t)n_cand);
+        }
+    }
     return PCFIT_OK;
 }
 

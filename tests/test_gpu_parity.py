@@ -735,3 +735,21 @@ def test_resident_scan_gives_the_same_analysis():
         assert np.isnan(scan.z_min) and np.isnan(scan.z_max)
     with pytest.raises(ValueError):
         CylinderAnalyzer(Config(z_min=1.0, z_max=9.0)).analyze_with_progress(DeviceScan(pts))
+
+
+def test_hybrid_with_all_points_as_candidates_in_a_large_batch():
+    """use_hull_vertices_only=False on 40 slices of 8000 points: 320 000 candidates come back (the results
+    then leave the device section by section); three slices are compared with the same call on the slice alone."""
+    x, y, off = R.make_slices(40, 8000, seed=23, outlier_frac=0.1)
+    h = F.hybrid_batch(x, y, off, max_trials=64, use_hull=False, want_profile=False)
+    assert np.all(h["status"] == 0) and h["cand_offsets"][-1] > 300_000
+    for s in (0, 17, 39):
+        sl = slice(off[s], off[s + 1])
+        one = F.hybrid_batch(x[sl], y[sl], None, max_trials=64, use_hull=False, want_profile=False)
+        c0, c1 = h["cand_offsets"][s], h["cand_offsets"][s + 1]
+        for k in ("cand_x", "cand_y", "mask", "radius", "theta"):
+            assert np.array_equal(h[k][c0:c1], one[k]), k
+        assert np.array_equal(h["fit"][s], one["fit"][0]) and np.array_equal(h["ov"][s], one["ov"][0])
+        assert h["argmax"][s] == one["argmax"][0] and h["argmin"][s] == one["argmin"][0]
+        uniq = R.unique_rows(np.stack([x[sl], y[sl]], 1))
+        assert np.array_equal(np.stack([one["cand_x"], one["cand_y"]], 1), uniq)
