@@ -41,6 +41,24 @@
 namespace pcfit {
 
 constexpr int HULL_BLOCK = 1024;
+
+// Optional phase timing (tools only; -DPCFIT_PHASE_CLOCK): thread 0 of every workgroup adds the clocks
+// spent between marks to g_hull_phase[k].
+#ifdef PCFIT_PHASE_CLOCK
+__device__ unsigned long long g_hull_phase[8];
+#define HULL_MARK(k)                                                                   \
+    do {                                                                               \
+        if (threadIdx.x == 0) {                                                        \
+            const long long now_ = clock64();                                          \
+            atomicAdd(&g_hull_phase[k], (unsigned long long)(now_ - hull_last_));      \
+            hull_last_ = now_;                                                         \
+        }                                                                              \
+    } while (0)
+#define HULL_MARK_INIT() long long hull_last_ = clock64()
+#else
+#define HULL_MARK(k) do { } while (0)
+#define HULL_MARK_INIT() do { } while (0)
+#endif
 constexpr int HULL_LDS_CAP = 8192;
 
 __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e)
@@ -129,12 +147,26 @@ __device__ __forceinline__ int chain_chunk(const double *px, const double *py, I
     const int64_t end = min(L, begin + c);
     IdxT *st = list + begin;
     int k = 0;
+    // the two points on top of the stack stay in registers: a push costs no load, a pop one
+    double ax = 0.0, ay = 0.0, bx = 0.0, by = 0.0;          // st[k-2], st[k-1]
     for (int64_t i = begin; i < end; i++) {
         const IdxT v = list[i];
         const double vx = px[v], vy = py[v];
-        while (k >= 2 && orient_sign(px[st[k - 2]], py[st[k - 2]], px[st[k - 1]], py[st[k - 1]], vx, vy) <= 0)
+        while (k >= 2 && orient_sign(ax, ay, bx, by, vx, vy) <= 0) {
             k--;
+            bx = ax;
+            by = ay;
+            if (k >= 2) {
+                const IdxT u = st[k - 2];
+                ax = px[u];
+                ay = py[u];
+            }
+        }
         st[k++] = v;
+        ax = bx;
+        ay = by;
+        bx = vx;
+        by = vy;
     }
     return k;
 }
@@ -144,7 +176,8 @@ template <class IdxT>
 __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, int64_t L, int64_t *pong,
                                 int *scratch)
 {
-    int64_t c = 16;
+    constexpr int C0 = 16;
+    int64_t c = C0;
     while (true) {
         if (L <= c) {                                   // one thread finishes
             __shared__ int last_k;
@@ -158,16 +191,30 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
         while ((L + c - 1) / c > HULL_BLOCK)
             c <<= 1;
         const int kept = chain_chunk(px, py, list, L, c);
-        int total;
-        const int at = block_exscan(kept, scratch, &total);
-        // compact through the slice's own hull output buffer (global memory)
         const int64_t begin = (int64_t)threadIdx.x * c;
-        for (int i = 0; i < kept; i++)
-            pong[at + i] = (int64_t)list[begin + i];
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < total; i += HULL_BLOCK)
-            list[i] = (IdxT)pong[i];
-        __syncthreads();
+        int total;
+        if (c == C0) {
+            // chunks of the first size: a thread's survivors wait in its registers while the others read theirs
+            IdxT mine[C0];
+#pragma unroll
+            for (int i = 0; i < C0; i++)
+                mine[i] = i < kept ? list[begin + i] : (IdxT)0;
+            const int at = block_exscan(kept, scratch, &total);     // (its barriers end all reads of the list)
+#pragma unroll
+            for (int i = 0; i < C0; i++)
+                if (i < kept)
+                    list[at + i] = mine[i];
+            __syncthreads();
+        } else {
+            const int at = block_exscan(kept, scratch, &total);
+            // compact through the slice's own hull output buffer (global memory)
+            for (int i = 0; i < kept; i++)
+                pong[at + i] = (int64_t)list[begin + i];
+            __syncthreads();
+            for (int64_t i = threadIdx.x; i < total; i += HULL_BLOCK)
+                list[i] = (IdxT)pong[i];
+            __syncthreads();
+        }
         if (2 * (int64_t)total > L)
             c <<= 1;
         L = total;
@@ -388,6 +435,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
     int64_t *pong = hull_idx + off;
     const int tid = threadIdx.x;
+    HULL_MARK_INIT();
     if (tid == 0) {
         n_unique[s] = 0;
         n_hull[s] = 0;
@@ -400,6 +448,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         }
     }
     __syncthreads();
+    HULL_MARK(0);
 
     // ---- sort (ascending-only bitonic network, virtual +inf padding).  Strides are powers of two: the
     // partner indices come from shifts and masks on 32-bit values (n < 2^31).
@@ -433,6 +482,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         }
     }
 
+    HULL_MARK(1);
     // ---- unique: keep the first of every run of equal rows
     const int64_t per = (n + HULL_BLOCK - 1) / HULL_BLOCK;
     const int64_t b0 = min(n, (int64_t)tid * per), b1 = min(n, b0 + per);
@@ -467,6 +517,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         return;
     }
 
+    HULL_MARK(2);
     // ---- rank check (circle_fitting.py:14-19)
     {
         double s1[2] = {0.0, 0.0};
@@ -507,6 +558,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         }
     }
 
+    HULL_MARK(3);
     // ---- hull: lower chain (left to right), then upper chain (right to left)
     for (int64_t i = tid; i < m; i += HULL_BLOCK)
         list[i] = (IdxT)i;
@@ -520,6 +572,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         list[i] = (IdxT)(m - 1 - i);
     __syncthreads();
     const int64_t hu = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
+    HULL_MARK(4);
     const int64_t h = (hl - 1) + (hu - 1);
     // both chains end on the other's first vertex: drop each chain's last entry
     for (int64_t i = tid; i < hl - 1; i += HULL_BLOCK)
@@ -648,3 +701,18 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
     }
     return PCFIT_OK;
 }
+
+#ifdef PCFIT_PHASE_CLOCK
+// tools only: clocks per phase of unique_hull_kernel (load, sort, unique, rank check, chains)
+PCFIT_API int pcfit_debug_hull_phases(int64_t *out8, int reset)
+{
+    PCFIT_ENTER();
+    PCFIT_HIP(hipDeviceSynchronize());
+    PCFIT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pcfit::g_hull_phase), 8 * sizeof(int64_t)));
+    if (reset) {
+        int64_t zero[8] = {0};
+        PCFIT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pcfit::g_hull_phase), zero, sizeof(zero)));
+    }
+    return PCFIT_OK;
+}
+#endif
