@@ -753,3 +753,28 @@ def test_hybrid_with_all_points_as_candidates_in_a_large_batch():
         assert h["argmax"][s] == one["argmax"][0] and h["argmin"][s] == one["argmin"][0]
         uniq = R.unique_rows(np.stack([x[sl], y[sl]], 1))
         assert np.array_equal(np.stack([one["cand_x"], one["cand_y"]], 1), uniq)
+
+
+def test_calls_from_several_threads_at_once():
+    """The reference enters the numerics from a pool of threads (analyzer.py:203-207) and ctypes drops the GIL
+    during a call: concurrent calls into the library (shared block cache, shared sampling-table cache, one
+    null stream) must give what the same calls give one after the other."""
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
+    for k in range(12):
+        x, y, off = R.make_slices(3 + k % 4, 700 + 450 * k, seed=100 + k, outlier_frac=0.05 * (k % 3))
+        jobs.append((x, y, off))
+
+    def run(job):
+        x, y, off = job
+        h = F.hybrid_batch(x, y, off, max_trials=500, want_profile=False)
+        k, _ = F.kasa_batch(x, y, off)
+        return h["fit"], h["mask"], h["cand_x"], k
+
+    serial = [run(j) for j in jobs]
+    for _ in range(2):
+        with ThreadPoolExecutor(6) as pool:
+            parallel = list(pool.map(run, jobs))
+        for a, b in zip(serial, parallel):
+            for u, v in zip(a, b):
+                assert np.array_equal(u, v, equal_nan=True)
