@@ -1,0 +1,156 @@
+"""Randomised parity sweep of the GPU entry points against the C restatement (run by hand on a GPU box:
+``python tests/fuzz_parity.py [rounds] [first_seed]``; not collected by pytest).  Every round draws a batch of
+slices whose lengths sit on and around the kernels' shape boundaries and whose content runs from clean rings to
+degenerate sets, and compares stage by stage.  Prints one line per mismatch and a summary; exit code 1 on any."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import native as N           # noqa: E402
+from oracle import ref_np as R           # noqa: E402
+from pointcloud_amd import _ffi as F     # noqa: E402
+
+EDGE_SIZES = [0, 1, 2, 3, 4, 5, 7, 63, 64, 65, 127, 255, 256, 257, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097,
+              8191, 8192, 8193, 9000, 16384, 20001]
+bad = []
+
+
+def note(seed, s, what, detail=""):
+    bad.append((seed, s, what))
+    print(f"MISMATCH seed {seed} slice {s}: {what} {detail}", flush=True)
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+def make_slice(g, n):
+    kind = g.choice(["ring", "ring", "ring", "outliers", "arc", "dups", "line", "same", "tiny", "far", "grid"])
+    th = g.uniform(0, 2 * np.pi, n)
+    r = 10.0 + g.normal(0, 0.05, n)
+    c = np.array([3.0, -2.0])
+    if kind == "outliers":
+        m = g.random(n) < g.uniform(0.02, 0.4)
+        r[m] = g.uniform(0, 14.0, int(m.sum()))
+    if kind == "arc":
+        th = g.uniform(0.3, 0.3 + g.uniform(0.2, 3.0), n)
+    xy = np.stack([c[0] + r * np.cos(th), c[1] + r * np.sin(th)], 1)
+    if kind == "dups" and n > 4:
+        xy[g.integers(0, n, n // 3)] = xy[g.integers(0, n, n // 3)]
+    if kind == "line":
+        t = g.normal(0, 5, n)
+        xy = np.stack([1.0 + 2.0 * t, -3.0 + 0.5 * t], 1)
+    if kind == "same":
+        xy = np.tile([[1.25, -7.5]], (n, 1))
+    if kind == "tiny":
+        xy = (xy - c) * 1e-6
+    if kind == "far":
+        xy = xy + np.array([1.0e6, -2.0e6])
+    if kind == "grid":
+        xy = np.round(xy * 8.0) / 8.0                    # many exact duplicates and collinear runs
+    return kind, np.ascontiguousarray(xy)
+
+
+def one_round(seed):
+    g = np.random.default_rng(seed)
+    S = int(g.integers(3, 14))
+    sizes = [int(g.choice(EDGE_SIZES)) if g.random() < 0.6 else int(g.integers(0, 9000)) for _ in range(S)]
+    kinds, sets = zip(*(make_slice(g, n) for n in sizes))
+    x = np.concatenate([s[:, 0] for s in sets]) if sum(sizes) else np.zeros(0)
+    y = np.concatenate([s[:, 1] for s in sets]) if sum(sizes) else np.zeros(0)
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+
+    kasa, kst = F.kasa_batch(x, y, off)
+    init = np.where(np.isfinite(kasa), kasa, 1.0)
+    lm, iters = F.lm_batch(x, y, off, init)
+    res = F.residuals_batch(x, y, off, init, bins=64, lo=-0.5, hi=0.5)
+    sel = F.angle_max_batch(x, y, off, init, bins=90)
+    uh = F.unique_hull_batch(x, y, off)
+    rs = F.ransac_batch(x, y, off, max_trials=150)
+    for s, xy in enumerate(sets):
+        n = len(xy)
+        tag = f"[{kinds[s]} n={n}]"
+        o0, o1 = off[s], off[s + 1]
+        # Kasa
+        st, k = N.kasa(xy[:, 0], xy[:, 1]) if n else (1, np.full(3, np.nan))
+        if n >= 3:
+            # (exactly collinear points: whether the determinant rounds to zero depends on the summation order)
+            if st != kst[s] and kinds[s] not in ("line", "same"):
+                note(seed, s, "kasa status", f"{tag} {kst[s]} vs {st}")
+            # (a million units off the origin a three- or four-point fit loses up to 1e-8: conditioning, both sides)
+            elif st == 0 and rel(kasa[s], k) > (1e-6 if kinds[s] == "far" else 1e-9) and kinds[s] not in ("line", "same"):
+                note(seed, s, "kasa value", f"{tag} {rel(kasa[s], k):.2e}")
+        # LM from the same start
+        if n >= 3 and kinds[s] not in ("line", "same"):
+            want, it, acc = N.lm(xy[:, 0], xy[:, 1], init[s])
+            tol = 1e-9 if kinds[s] in ("ring", "dups", "tiny", "grid") else 1e-6
+            scale = np.abs(want).max() if kinds[s] == "far" else None
+            err = float(np.max(np.abs(lm[s] - want)) / scale) if scale else rel(lm[s], want)
+            if not (err <= tol):
+                note(seed, s, "lm value", f"{tag} {err:.2e}")
+        # residual statistics about the start circle
+        if n >= 1:
+            want = N.residuals(xy, *init[s], bins=64, lo=-0.5, hi=0.5)
+            if not np.array_equal(res["hist"][s], want["hist"]):
+                note(seed, s, "histogram", tag)
+            if res["argmax"][s] != want["argmax"] or res["argmin"][s] != want["argmin"]:
+                note(seed, s, "argmax/argmin", tag)
+            if res["rmax"][s] != want["rmax"] or res["rmin"][s] != want["rmin"]:
+                note(seed, s, "rmax/rmin", tag)
+            if not np.array_equal(res["dr"][o0:o1], want["dr"]):
+                note(seed, s, "delta r", tag)
+            if np.max(np.abs(res["theta"][o0:o1] - want["theta"])) > 2e-15:
+                note(seed, s, "theta", tag)
+            want_sel = N.angle_max(xy, init[s][0], init[s][1], bins=90)
+            if not np.array_equal(sel[s], want_sel):
+                # a point within an ulp of a bin edge may land on either side (atan2 of host and device)
+                th = want["theta"]
+                near = np.min(np.abs((th / (2 * np.pi / 90)) - np.round(th / (2 * np.pi / 90)))) < 1e-9
+                if not near:
+                    note(seed, s, "angle_max", tag)
+        # unique + hull
+        if n >= 1:
+            uniq = N.sort_unique(xy)
+            nu, nh = int(uh["n_unique"][s]), int(uh["n_hull"][s])
+            got_u = np.stack([uh["ux"][o0:o0 + nu], uh["uy"][o0:o0 + nu]], 1)
+            if len(uniq) >= 3 and N.has_2d_variation(uniq) and uh["status"][s] == 0:
+                hv = uniq[N.hull(uniq)]
+                if not np.array_equal(got_u[uh["hull_idx"][o0:o0 + nh]], hv):
+                    note(seed, s, "hull", tag)
+                if n <= 8192 and not np.array_equal(got_u, uniq):
+                    note(seed, s, "unique", tag)
+            elif len(uniq) >= 3 and N.has_2d_variation(uniq) != (uh["status"][s] == 0) and kinds[s] not in ("line",):
+                note(seed, s, "rank check", f"{tag} status {uh['status'][s]}")
+        # RANSAC
+        if n >= 3:
+            want = N.ransac(xy, trials=150)
+            ok_gpu = rs["status"][s] == 0
+            if (want["status"] == 0) != ok_gpu:
+                note(seed, s, "ransac status", f"{tag} {rs['status'][s]} vs {want['status']}")
+            elif ok_gpu:
+                if rs["score"][s] != want["score"] or rs["best_trial"][s] != want["best_trial"]:
+                    note(seed, s, "ransac score/trial", f"{tag} {rs['score'][s]}/{rs['best_trial'][s]} vs "
+                                                        f"{want['score']}/{want['best_trial']}")
+                elif not np.array_equal(rs["mask"][o0:o1], want["mask"]):
+                    note(seed, s, "ransac mask", tag)
+    return S, sum(sizes)
+
+
+if __name__ == "__main__":
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    t0 = time.perf_counter()
+    slices = points = 0
+    for k in range(rounds):
+        s, p = one_round(first + k)
+        slices += s
+        points += p
+        if (k + 1) % 10 == 0:
+            print(f"round {k + 1}/{rounds}: {slices} slices, {points} points, {len(bad)} mismatches, "
+                  f"{time.perf_counter() - t0:.0f} s", flush=True)
+    print(f"done: {rounds} rounds, {slices} slices, {points} points, {len(bad)} mismatches")
+    sys.exit(1 if bad else 0)
