@@ -778,3 +778,45 @@ def test_calls_from_several_threads_at_once():
         for a, b in zip(serial, parallel):
             for u, v in zip(a, b):
                 assert np.array_equal(u, v, equal_nan=True)
+
+
+def test_device_entry_points_can_be_captured_in_a_hip_graph():
+    """The _dev calls only enqueue (no allocation, no synchronisation): a serving loop may capture one into a
+    HIP graph and replay it.  The fused fit + residual launch is captured on a side stream, replayed on fresh
+    inputs and compared with direct calls."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    S, n, H = 300, 4096, 64
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    x0, y0, off = R.make_slices(S, n, seed=41)
+    x1, y1, _ = R.make_slices(S, n, seed=42, outlier_frac=0.1)
+    dx, dy, doff, dedge = t(x0), t(y0), t(off), t(np.linspace(-0.5, 0.5, H + 1))
+    kasa, fit = torch.empty(S, 3, dtype=torch.float64, device=dev), torch.empty(S, 3, dtype=torch.float64, device=dev)
+    it, st_ = torch.empty(S, 4, dtype=torch.int32, device=dev), torch.empty(S, dtype=torch.int32, device=dev)
+    hist = torch.zeros(S, H, dtype=torch.int64, device=dev)
+    rmm, amm = torch.empty(S, 2, dtype=torch.float64, device=dev), torch.empty(S, 2, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream()
+
+    def launch(stream):
+        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa),
+                                                      p(fit), p(it), p(st_), H, p(dedge), p(hist), p(rmm), p(amm),
+                                                      C.c_void_p(stream.cuda_stream)))
+
+    launch(side)                                         # (first call outside the capture: one-time function attributes)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        launch(side)
+    for xs, ys in ((x1, y1), (x0, y0)):
+        dx.copy_(t(xs))
+        dy.copy_(t(ys))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        got = [a.clone() for a in (kasa, fit, it, st_, hist, rmm, amm)]
+        launch(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        for a, b in zip(got, (kasa, fit, it, st_, hist, rmm, amm)):
+            assert torch.equal(a, b) or (a.is_floating_point() and torch.allclose(a, b, rtol=0, atol=0, equal_nan=True))
