@@ -48,6 +48,10 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
 int pool_get(size_t bytes, void **ptr, size_t *got);
 void pool_put(void *ptr, size_t bytes);
 int pool_release();
+// Large host-to-device copies from pageable memory: several host threads copy chunks into pinned staging
+// buffers, each chunk followed by its own asynchronous transfer (api.hip).  Returns when the data is in place.
+int upload_staged(void *dst_dev, const void *src_host, size_t bytes);
+constexpr size_t STAGED_UPLOAD_MIN = (size_t)32 << 20;
 
 // Device buffer that returns itself: the host-pointer entry points own all the
 // device memory they touch for the duration of one call.
@@ -68,6 +72,8 @@ struct DevBuf {
     {
         int rc = alloc(n);
         if (rc) return rc;
+        if (n >= STAGED_UPLOAD_MIN && st == nullptr)
+            return upload_staged(p, src, n);
         if (n) PCFIT_HIP(hipMemcpyAsync(p, src, n, hipMemcpyHostToDevice, st));
         return PCFIT_OK;
     }
