@@ -302,6 +302,54 @@ int upload_staged(void *dst, const void *src, size_t bytes)
     return PCFIT_OK;
 }
 
+int download_staged(void *dst, const void *src, size_t bytes)
+{
+    static const bool off = [] { const char *e = getenv("PCFIT_STAGED_UPLOAD"); return e && *e == '0'; }();
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    std::unique_lock<std::mutex> lock(g_stage_mu);
+    if (off || !stage_make(dev)) {
+        lock.unlock();
+        PCFIT_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+        return PCFIT_OK;
+    }
+    PCFIT_HIP(hipStreamSynchronize(nullptr));              // what the null stream still computes is what is fetched
+    const size_t chunks = (bytes + STAGE_CHUNK - 1) / STAGE_CHUNK;
+    int rc[STAGE_T] = {};
+    auto work = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { rc[t] = 1; return; }
+        // two buffers per thread: the transfer of the next chunk runs while this one is copied out
+        auto fetch = [&](size_t c, int b) {
+            const size_t at = c * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - at);
+            return hipMemcpyAsync(g_stage.buf[b], static_cast<const char *>(src) + at, len, hipMemcpyDeviceToHost,
+                                  g_stage.st[t]) == hipSuccess &&
+                   hipEventRecord(g_stage.ev[b], g_stage.st[t]) == hipSuccess;
+        };
+        size_t use = 0;
+        if (t < (int)chunks && !fetch(t, 2 * t)) { rc[t] = 1; return; }
+        for (size_t c = t; c < chunks; c += STAGE_T, use++) {
+            const int b = 2 * t + (int)(use & 1);
+            if (c + STAGE_T < chunks && !fetch(c + STAGE_T, 2 * t + (int)((use + 1) & 1))) { rc[t] = 1; return; }
+            if (hipEventSynchronize(g_stage.ev[b]) != hipSuccess) { rc[t] = 1; return; }
+            const size_t at = c * STAGE_CHUNK, len = std::min(STAGE_CHUNK, bytes - at);
+            memcpy(static_cast<char *>(dst) + at, g_stage.buf[b], len);
+        }
+    };
+    std::thread pool[STAGE_T - 1];
+    for (int t = 1; t < STAGE_T; t++)
+        pool[t - 1] = std::thread(work, t);
+    work(0);
+    for (auto &th : pool)
+        th.join();
+    for (int t = 0; t < STAGE_T; t++)
+        if (rc[t]) {
+            (void)hipGetLastError();
+            set_error("staged download of %zu bytes failed", bytes);
+            return PCFIT_ERR_HIP;
+        }
+    return PCFIT_OK;
+}
+
 int pool_release()
 {
     {

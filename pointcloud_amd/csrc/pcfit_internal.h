@@ -51,6 +51,7 @@ int pool_release();
 // Large host-to-device copies from pageable memory: several host threads copy chunks into pinned staging
 // buffers, each chunk followed by its own asynchronous transfer (api.hip).  Returns when the data is in place.
 int upload_staged(void *dst_dev, const void *src_host, size_t bytes);
+int download_staged(void *dst_host, const void *src_dev, size_t bytes);      // the same, the other way
 constexpr size_t STAGED_UPLOAD_MIN = (size_t)32 << 20;
 
 // Device buffer that returns itself: the host-pointer entry points own all the
@@ -79,6 +80,8 @@ struct DevBuf {
     }
     int download(void *dst, size_t n, hipStream_t st) const
     {
+        if (n >= STAGED_UPLOAD_MIN && dst && st == nullptr)
+            return download_staged(dst, p, n);
         if (n && dst) PCFIT_HIP(hipMemcpyAsync(dst, p, n, hipMemcpyDeviceToHost, st));
         return PCFIT_OK;
     }
