@@ -336,6 +336,16 @@ int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const
                                int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
                                int64_t cand_capacity);
 
+/* ---- the step after the path: CSV rows (host cores only) -------------------- */
+/* The body of slice_points.csv as save_results writes it (utils/data_io.py:43-46:
+ * to_csv(index=False, float_format="%.6f")): n_cols columns of n_rows doubles, one
+ * column after the other in cols; is_int[c] != 0 prints column c as an integer;
+ * NaN gives an empty field; fields joined by ',', rows ended by '\n'.  *length
+ * receives the byte count; PCFIT_ERR_INVALID if capacity is short (call again
+ * with *length bytes). */
+int pcfit_format_csv_rows(const double *cols, int64_t n_rows, int32_t n_cols, const uint8_t *is_int,
+                          int32_t n_threads, char *out, size_t capacity, size_t *length);
+
 #ifdef __cplusplus
 }
 #endif

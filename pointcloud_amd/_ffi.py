@@ -85,6 +85,7 @@ SIGNATURES = {
     "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
                            + [_i64]),
     "pcfit_count_text_lines": (C.c_int, [C.c_char_p, _sz, _i32, _vp]),
+    "pcfit_format_csv_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
     "pcfit_parse_xyz_text": (C.c_int, [C.c_char_p, _sz, _i32, _vp, _vp, _i64, _vp]),
     "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
     "pcfit_scan_free": (C.c_int, [_vp]),
@@ -402,3 +403,20 @@ def parse_xyz_text(data: bytes, n_threads: int = 0):
     flag = np.empty(cap, np.uint8)
     check(lib().pcfit_parse_xyz_text(data, len(data), n_threads, _p(rows), _p(flag), cap, C.addressof(n)))
     return rows[:n.value], flag[:n.value].astype(bool)
+
+
+def format_csv_rows(columns, is_int, n_threads: int = 0) -> bytes:
+    """CSV body ('%.6f' floats, integers, NaN -> empty) of equally long columns (see pcfit_format_csv_rows)."""
+    cols = np.ascontiguousarray(np.stack([np.asarray(c, np.float64) for c in columns]))
+    flags = np.ascontiguousarray(is_int, np.uint8)
+    n_cols, n_rows = cols.shape
+    cap = max(n_rows * n_cols * 14, 64)
+    n = _sz(0)
+    while True:
+        out = np.empty(cap, np.uint8)
+        rc = lib().pcfit_format_csv_rows(_p(cols), n_rows, n_cols, _p(flags), n_threads, _p(out), cap, C.addressof(n))
+        if rc != 0 and n.value > cap:
+            cap = n.value
+            continue
+        check(rc)
+        return out[:n.value].tobytes()

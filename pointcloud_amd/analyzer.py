@@ -134,8 +134,6 @@ class CylinderAnalyzer:
         """Process entire point cloud file (reference: analyzer.py:131-179).  Writes
         slice_results.csv and slice_points.csv into the working directory; the
         reference's matplotlib figures are not produced."""
-        import pandas as pd
-
         points = load_txt_points(file_path)
         z_min, z_max = points[:, 2].min(), points[:, 2].max()
         print(f"Z range in data: [{z_min:.3f}, {z_max:.3f}]  "
@@ -148,7 +146,7 @@ class CylinderAnalyzer:
                 print(warn)
                 continue
             results.append(res)
-            frames.append(pd.DataFrame(edge))
+            frames.append(edge)                       # (columns of one slice; save_results takes them as they are)
         if results:
             save_results(results, frames, ".")
         return results

@@ -9,6 +9,7 @@
 // to it.  The result is therefore the reference's for every input, fast for the usual ones.
 #include <charconv>
 #include <cstring>
+#include <string>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -242,5 +243,54 @@ PCFIT_API int pcfit_parse_xyz_text(const char *text, size_t n_bytes, int32_t n_t
         at += sink[t].n;
     }
     *n_rows = at;
+    return PCFIT_OK;
+}
+
+// ---- the step after the path: CSV rows with '%.6f' floats ------------------------------------
+// pandas' to_csv(float_format="%.6f") formats every float through Python's % operator (save_results,
+// utils/data_io.py:37,46): correctly rounded fixed notation, the same digits printf gives.  cols holds n_cols
+// columns of n_rows doubles each, one after the other; is_int[c] marks columns printed as integers; NaN
+// becomes an empty field (pandas' na_rep).  Rows are formatted by several host threads.
+PCFIT_API int pcfit_format_csv_rows(const double *cols, int64_t n_rows, int32_t n_cols, const uint8_t *is_int,
+                                    int32_t n_threads, char *out, size_t capacity, size_t *length)
+{
+    PCFIT_REQUIRE(length && n_rows >= 0 && n_cols >= 1 && (n_rows == 0 || (cols && is_int)),
+                  "format_csv_rows: bad arguments");
+    const int T = (int)std::min<int64_t>(std::max<int64_t>(n_rows / 2048, 1),
+                                         n_threads > 0 ? n_threads
+                                                       : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+    std::vector<std::string> piece(T);
+    run_pieces(T, [&](int t) {
+        const int64_t r0 = n_rows * t / T, r1 = n_rows * (t + 1) / T;
+        std::string &o = piece[t];
+        o.reserve((size_t)(r1 - r0) * (size_t)n_cols * 12);
+        char tmp[400];
+        for (int64_t r = r0; r < r1; r++) {
+            for (int32_t c = 0; c < n_cols; c++) {
+                const double v = cols[(size_t)c * (size_t)n_rows + (size_t)r];
+                if (c)
+                    o.push_back(',');
+                if (v != v)
+                    continue;
+                const int k = is_int[c] ? snprintf(tmp, sizeof tmp, "%lld", (long long)v)
+                                        : snprintf(tmp, sizeof tmp, "%.6f", v);
+                o.append(tmp, (size_t)k);
+            }
+            o.push_back('\n');
+        }
+    });
+    size_t total = 0;
+    for (const std::string &o : piece)
+        total += o.size();
+    *length = total;
+    if (total > capacity || (total && !out)) {
+        set_error("format_csv_rows: %zu bytes needed, %zu offered", total, capacity);
+        return PCFIT_ERR_INVALID;
+    }
+    size_t at = 0;
+    for (const std::string &o : piece) {
+        memcpy(out + at, o.data(), o.size());
+        at += o.size();
+    }
     return PCFIT_OK;
 }

@@ -49,9 +49,44 @@ def load_txt_points(path: str, n_threads: int = 0) -> np.ndarray:
     return np.ascontiguousarray(rows, dtype=np.float64)
 
 
+def _points_csv(points: list):
+    """slice_points.csv as bytes, or None when the frames are not plain numeric columns (then pandas writes it).
+    ``points``: DataFrames or dicts of equally long columns with the same keys."""
+    from .. import _ffi
+
+    names = list(points[0].keys())
+    cols, is_int = [], []
+    for name in names:
+        parts = []
+        for f in points:
+            if list(f.keys()) != names:
+                return None
+            v = f[name]
+            n = next(len(w) for w in f.values() if np.ndim(w) > 0) if isinstance(f, dict) else len(f)
+            parts.append(np.full(n, v) if np.ndim(v) == 0 else np.asarray(v))
+        col = np.concatenate(parts)
+        if col.dtype.kind in "iub":
+            if col.size and np.abs(col.astype(np.float64)).max() >= 2.0**53:
+                return None
+            is_int.append(1)
+        elif col.dtype.kind == "f":
+            is_int.append(0)
+        else:
+            return None
+        cols.append(col.astype(np.float64))
+    if "z_center" not in names or "theta" not in names:
+        return None
+    order = np.lexsort((cols[names.index("theta")], cols[names.index("z_center")]))     # stable, like sort_values
+    body = _ffi.format_csv_rows([c[order] for c in cols], is_int)
+    return (",".join(names) + "\n").encode() + body
+
+
 def save_results(results: list, points: list, output_dir: str):
     """slice_results.csv (sorted by z_center) and slice_points.csv (sorted by
-    z_center, theta), '%.6f' floats.  Reference: utils/data_io.py:29-47."""
+    z_center, theta), '%.6f' floats.  Reference: utils/data_io.py:29-47.  The
+    points file - the big one - is formatted by the library on all host cores
+    when its columns are plain numbers; ``points`` may hold DataFrames (as in the
+    reference) or dicts of columns."""
     import pandas as pd
 
     if not results:
@@ -59,5 +94,12 @@ def save_results(results: list, points: list, output_dir: str):
     table = pd.DataFrame(results).sort_values("z_center").reset_index(drop=True)
     table.to_csv(os.path.join(output_dir, "slice_results.csv"), index=False, float_format="%.6f")
     if points:
-        edge = pd.concat(points, ignore_index=True).sort_values(["z_center", "theta"]).reset_index(drop=True)
-        edge.to_csv(os.path.join(output_dir, "slice_points.csv"), index=False, float_format="%.6f")
+        path = os.path.join(output_dir, "slice_points.csv")
+        data = _points_csv(points)
+        if data is not None:
+            with open(path, "wb") as fh:
+                fh.write(data)
+            return
+        frames = [f if isinstance(f, pd.DataFrame) else pd.DataFrame(f) for f in points]
+        edge = pd.concat(frames, ignore_index=True).sort_values(["z_center", "theta"]).reset_index(drop=True)
+        edge.to_csv(path, index=False, float_format="%.6f")

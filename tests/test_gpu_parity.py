@@ -831,3 +831,32 @@ def test_large_transfers_arrive_intact():
     off, x, y, perm = F.bin_slices(pts, [-1.0], [2.0])
     assert off[-1] == n and np.array_equal(perm, np.arange(n))
     assert np.array_equal(x, pts[:, 0]) and np.array_equal(y, pts[:, 1])
+
+
+def test_analyze_file_writes_the_reference_formats(tmp_path, monkeypatch, capsys):
+    """analyze_file: text in (native loader), slice_results.csv and slice_points.csv out; the points file, written
+    by the library's formatter, equals byte for byte what pandas writes from the same columns."""
+    import pandas as pd
+    from pointcloud_amd import Config, CylinderAnalyzer
+    pts = R.make_cylinder(120_000, 12, seed=51, outlier_frac=0.02)
+    scan = tmp_path / "scan.txt"
+    np.savetxt(scan, pts, fmt="%.6f", header="x y z")
+    monkeypatch.chdir(tmp_path)
+    az = CylinderAnalyzer(Config(min_points_per_slice=500))
+    results = az.analyze_file(str(scan))
+    out = capsys.readouterr().out
+    assert "Z range in data" in out and len(results) >= 10
+    loaded = np.loadtxt(scan)
+    again = az.analyze_with_progress(loaded)
+    assert [r["z_center"] for r in results] == [r["z_center"] for r in again]
+    assert results[3]["boundary_points"] == again[3]["boundary_points"] and results[3]["R"] == again[3]["R"]
+    res_csv = pd.read_csv(tmp_path / "slice_results.csv")
+    assert len(res_csv) == len(results) and list(res_csv.columns) == list(results[0].keys())
+    # the same edge columns through pandas
+    frames = []
+    for r in results:
+        (pack, edge, warn) = az.process_slice(loaded, r["z_center"])
+        frames.append(edge)
+    want = pd.concat(frames, ignore_index=True).sort_values(["z_center", "theta"]).reset_index(drop=True)
+    want_bytes = want.to_csv(index=False, float_format="%.6f").encode()
+    assert (tmp_path / "slice_points.csv").read_bytes() == want_bytes
