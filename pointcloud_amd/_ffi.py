@@ -84,9 +84,9 @@ SIGNATURES = {
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
                            + [_i64]),
-    "pcfit_count_text_lines": (C.c_int, [C.c_char_p, _sz, _i32, _vp]),
+    "pcfit_count_text_lines": (C.c_int, [_vp, _sz, _i32, _vp]),
     "pcfit_format_csv_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
-    "pcfit_parse_xyz_text": (C.c_int, [C.c_char_p, _sz, _i32, _vp, _vp, _i64, _vp]),
+    "pcfit_parse_xyz_text": (C.c_int, [_vp, _sz, _i32, _vp, _vp, _i64, _vp]),
     "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
     "pcfit_scan_free": (C.c_int, [_vp]),
     "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
@@ -394,14 +394,16 @@ def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_i
                 argmax=amm[:, 0], argmin=amm[:, 1], ov=ov, dev_uniform=dev, grid_len=K)
 
 
-def parse_xyz_text(data: bytes, n_threads: int = 0):
-    """Rows of the XYZ text ``data`` (see pcfit_parse_xyz_text): (rows (n,3), deferred (n,) bool)."""
+def parse_xyz_text(data, n_threads: int = 0):
+    """Rows of the XYZ text ``data`` (bytes or any buffer, e.g. a memory-mapped file; see pcfit_parse_xyz_text):
+    (rows (n,3), deferred (n,) bool)."""
+    raw = np.frombuffer(data, np.uint8)
     n = C.c_int64(0)
-    check(lib().pcfit_count_text_lines(data, len(data), n_threads, C.addressof(n)))
+    check(lib().pcfit_count_text_lines(_p(raw), raw.size, n_threads, C.addressof(n)))
     cap = n.value
     rows = np.empty((cap, 3))
     flag = np.empty(cap, np.uint8)
-    check(lib().pcfit_parse_xyz_text(data, len(data), n_threads, _p(rows), _p(flag), cap, C.addressof(n)))
+    check(lib().pcfit_parse_xyz_text(_p(raw), raw.size, n_threads, _p(rows), _p(flag), cap, C.addressof(n)))
     return rows[:n.value], flag[:n.value].astype(bool)
 
 

@@ -30,8 +30,11 @@ def load_txt_points(path: str, n_threads: int = 0) -> np.ndarray:
     any other content come back flagged and get the literal rule here."""
     from .. import _ffi
 
+    import mmap
+
     with open(path, "rb") as fh:
-        data = fh.read()
+        # the file's pages are parsed where the page cache holds them (no copy into a bytes object)
+        data = mmap.mmap(fh.fileno(), 0, access=mmap.ACCESS_READ) if os.fstat(fh.fileno()).st_size else b""
     rows, deferred = _ffi.parse_xyz_text(data, n_threads)
     idx = np.flatnonzero(deferred)
     if idx.size:
