@@ -135,7 +135,9 @@ class CylinderAnalyzer:
         slice_results.csv and slice_points.csv into the working directory; the
         reference's matplotlib figures are not produced."""
         points = load_txt_points(file_path)
-        z_min, z_max = points[:, 2].min(), points[:, 2].max()
+        # the scan goes to the GPU once; its z range comes back from there
+        points = _ffi.DeviceScan(points)
+        z_min, z_max = np.float64(points.z_min), np.float64(points.z_max)
         print(f"Z range in data: [{z_min:.3f}, {z_max:.3f}]  "
               f"| step={self.config.z_step}")
         dz = self.config.z_step / 2.0
