@@ -328,6 +328,11 @@ int pcfit_parse_xyz_text(const char *text, size_t n_bytes, int32_t n_threads, do
 typedef struct pcfit_scan pcfit_scan;
 int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan **scan, double *z_min_max);
 int pcfit_scan_free(pcfit_scan *scan);
+/* pcfit_bin_slices on the resident copy (analyzer.py:49-52 for any windows: the GUI's
+ * single-slice inspection, gui.py:1478-1501, reads one window of the loaded scan). */
+int pcfit_scan_bin_slices(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
+                          int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
+                          int64_t *total);
 int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
                                double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
                                double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "pcfit_parse_xyz_text": (C.c_int, [_vp, _sz, _i32, _vp, _vp, _i64, _vp]),
     "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
     "pcfit_scan_free": (C.c_int, [_vp]),
+    "pcfit_scan_bin_slices": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
                                    + [_vp] * 13 + [_i64, _i64]),
     "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
@@ -221,19 +222,32 @@ def angle_max_batch(x, y, offsets, cxcyr, bins=720):
 
 
 def bin_slices(points, z_lo, z_hi, want_perm=True):
-    pts = _arr(points, np.float64)
-    if pts.ndim != 2 or pts.shape[1] != 3:
-        raise ValueError("points must be (N,3)")
+    """Slices of ``points`` ((N,3) array, or a DeviceScan already on the GPU) in the windows [z_lo, z_hi]:
+    (offsets, x, y, perm or None)."""
+    resident = isinstance(points, DeviceScan)
+    if resident:
+        if not points._handle:
+            raise PcfitError("the DeviceScan was closed")
+        N = points.n_points
+    else:
+        pts = _arr(points, np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must be (N,3)")
+        N = pts.shape[0]
     z_lo = _arr(z_lo, np.float64)
     z_hi = _arr(z_hi, np.float64)
     S = z_lo.size
-    cap = 2 * pts.shape[0] + 1
+    cap = 2 * N + 1
     offsets = np.zeros(S + 1, np.int64)
     xo, yo = np.empty(cap), np.empty(cap)
     perm = np.empty(cap, np.int64) if want_perm else None
     total = C.c_int64(0)
-    check(lib().pcfit_bin_slices(_p(pts), pts.shape[0], _p(z_lo), _p(z_hi), S, _p(offsets), _p(xo), _p(yo), _p(perm),
-                                 cap, C.addressof(total)))
+    if resident:
+        check(lib().pcfit_scan_bin_slices(points._handle, _p(z_lo), _p(z_hi), S, _p(offsets), _p(xo), _p(yo), _p(perm),
+                                          cap, C.addressof(total)))
+    else:
+        check(lib().pcfit_bin_slices(_p(pts), N, _p(z_lo), _p(z_hi), S, _p(offsets), _p(xo), _p(yo), _p(perm),
+                                     cap, C.addressof(total)))
     t = total.value
     return offsets, xo[:t], yo[:t], (perm[:t] if want_perm else None)
 

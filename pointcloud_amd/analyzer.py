@@ -113,7 +113,8 @@ class CylinderAnalyzer:
         """Process a single slice of points (reference: analyzer.py:46-129)."""
         import pandas as pd
 
-        points = np.asarray(points, float)
+        if not isinstance(points, _ffi.DeviceScan):
+            points = np.asarray(points, float)
         hs = None if hull_start is None else np.array([hull_start], np.int64)
         offsets, x, y, h = self._run_windows(points, np.array([z_center], float), hs)
         n0 = int(offsets[1])

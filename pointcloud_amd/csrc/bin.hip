@@ -473,24 +473,23 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     return PCFIT_OK;
 }
 
-PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
-                               int64_t n_slices, int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
-                               int64_t capacity, int64_t *total)
+// count, offsets to the host, scatter, slices to the host: the scan is on the device already
+static int bin_resident(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
+                        int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
+                        int64_t *total)
 {
-    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
-    PCFIT_REQUIRE(z_lo && z_hi && offsets && total && (xyz || n_points == 0), "bin: null pointer");
+    PCFIT_REQUIRE(z_lo && z_hi && offsets && total, "bin: null pointer");
     double geom[3];
     PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
     hipStream_t st = nullptr;
-    DevBuf dxyz, dlo, dhi, doff, dws, dx, dy, dperm;
+    DevBuf dlo, dhi, doff, dws, dx, dy, dperm;
     const size_t ws_bytes = pcfit_bin_workspace_bytes(n_points, n_slices);
-    PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
     PCFIT_TRY(dlo.upload(z_lo, (size_t)n_slices * 8, st));
     PCFIT_TRY(dhi.upload(z_hi, (size_t)n_slices * 8, st));
     PCFIT_TRY(doff.alloc((size_t)(n_slices + 1) * 8));
     PCFIT_TRY(dws.alloc(ws_bytes));
-    PCFIT_TRY(pcfit_bin_count_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
+    PCFIT_TRY(pcfit_bin_count_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
                                   doff.as<int64_t>(), dws.p, dws.bytes, st));
     PCFIT_TRY(doff.download(offsets, (size_t)(n_slices + 1) * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
@@ -502,7 +501,7 @@ PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double
     PCFIT_TRY(dx.alloc((size_t)*total * 8));
     PCFIT_TRY(dy.alloc((size_t)*total * 8));
     if (perm) PCFIT_TRY(dperm.alloc((size_t)*total * 8));
-    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz.as<double>(), n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
+    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
                                     doff.as<int64_t>(), dx.as<double>(), dy.as<double>(),
                                     perm ? dperm.as<int64_t>() : nullptr, dws.p, dws.bytes, st));
     PCFIT_TRY(dx.download(x_out, (size_t)*total * 8, st));
@@ -510,4 +509,29 @@ PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double
     if (perm) PCFIT_TRY(dperm.download(perm, (size_t)*total * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_bin_slices(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                               int64_t n_slices, int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
+                               int64_t capacity, int64_t *total)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(n_points >= 0 && (xyz || n_points == 0), "bin: null pointer");
+    DevBuf dxyz;
+    PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, nullptr));
+    return bin_resident(dxyz.as<double>(), n_points, z_lo, z_hi, n_slices, offsets, x_out, y_out, perm, capacity,
+                        total);
+}
+
+PCFIT_API int pcfit_scan_bin_slices(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
+                                    int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
+                                    int64_t *total)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(scan, "bin: scan is null");
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    PCFIT_REQUIRE(dev == scan->device, "bin: the scan lives on device %d, the current device is %d", scan->device, dev);
+    return bin_resident(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, offsets, x_out, y_out, perm,
+                        capacity, total);
 }

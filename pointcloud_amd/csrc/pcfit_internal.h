@@ -88,6 +88,17 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+}  // namespace pcfit
+
+// A scan kept on the device between calls (the opaque pcfit_scan of the header).
+struct pcfit_scan {
+    pcfit::DevBuf xyz;
+    int64_t n_points = 0;
+    int device = 0;
+};
+
+namespace pcfit {
+
 #define PCFIT_TRY(expr)          \
     do {                         \
         int rc_ = (expr);        \

@@ -665,13 +665,6 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
                        dev_uniform, grid_len, total, st);
 }
 
-// A scan kept on the device between calls.
-struct pcfit_scan {
-    DevBuf xyz;
-    int64_t n_points = 0;
-    int device = 0;
-};
-
 namespace pcfit {
 
 constexpr int ZR_BLOCK = 256;

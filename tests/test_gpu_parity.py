@@ -722,6 +722,12 @@ def test_resident_scan_gives_the_same_analysis():
         seen = []
         got = az.analyze_with_progress(scan, progress_callback=seen.append)
         again = az.analyze_with_progress(scan)                  # the copy on the device is reusable
+        # single-slice inspection on the resident copy (gui.py:1478-1501)
+        zc = az.calculate_z_centers(pts)[7]
+        (res_a, cand_a, slc_a, fit_a, ov_a), edge_a, _ = az.process_slice(pts, zc)
+        (res_b, cand_b, slc_b, fit_b, ov_b), edge_b, _ = az.process_slice(scan, zc)
+        assert res_a == res_b and fit_a == fit_b and np.array_equal(slc_a, slc_b) and edge_a.equals(edge_b)
+        assert np.array_equal(ov_a["dev_uniform"], ov_b["dev_uniform"], equal_nan=True)
     assert seen[-1] == 100 and seen == sorted(seen)
     assert len(got) == len(want) == len(again) > 20
     for a, b, c in zip(want, got, again):
