@@ -268,7 +268,9 @@ int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, u
  * Out (capacity of every per-point array = offsets[S]):
  *     status S (0 ok / 1 / 2 / 3: the reference returns None), fit S*3,
  *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy); ux and uy may be NULL
- *                                when the caller does not want them copied back,
+ *                                when the caller does not want them: with hull candidates the
+ *                                hull kernel then drops provably interior points of slices
+ *                                longer than 1024 before sorting, and n_unique counts what it kept,
  *     cand_offsets S+1, cand_x, cand_y, mask     candidates_xy and inlier_mask,
  *     radius, theta              hypot and angle of every candidate about the fit,
  *     argmax_argmin S*2          candidate indices of the largest / smallest radius,

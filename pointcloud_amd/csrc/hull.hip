@@ -404,7 +404,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     double *__restrict__ ux, double *__restrict__ uy, int64_t *__restrict__ n_unique, int64_t *__restrict__ hull_idx,
     int64_t *__restrict__ n_hull, int32_t *__restrict__ status, const int64_t *__restrict__ hull_start,
     double *__restrict__ wsx, double *__restrict__ wsy, uint32_t *__restrict__ wslist,
-    uint32_t *__restrict__ wspark, const HullSliceAux *__restrict__ aux)
+    uint32_t *__restrict__ wspark, const HullSliceAux *__restrict__ aux, int hull_only)
 {
     extern __shared__ double lds_dyn[];
     __shared__ double red[9 * 16];
@@ -448,6 +448,70 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         }
     }
     __syncthreads();
+    // ---- a caller that wants hulls only: the interior filter of the long slices, here inside the LDS and
+    // before the sort (same thresholds, see hull_filter_slice_kernel); what is left is a few hundred points
+    if constexpr (IN_LDS) {
+        constexpr int K = HULL_SECTORS / 4;
+        constexpr int PER = HULL_LDS_CAP / HULL_BLOCK;
+        __shared__ unsigned long long fsect[K];
+        __shared__ double fthr[K];
+        __shared__ int fcount, fdead;
+        if (hull_only && !filtered && n > 1024) {
+            double s1[2] = {0.0, 0.0};
+            for (int64_t i = tid; i < n; i += HULL_BLOCK) {
+                s1[0] += px[i];
+                s1[1] += py[i];
+            }
+            block_sum<2>(s1, red);
+            const double cx = s1[0] / (double)n, cy = s1[1] / (double)n;
+            if (tid < K)
+                fsect[tid] = 0ull;
+            if (tid == 0) {
+                fcount = 0;
+                fdead = !(cx == cx && cy == cy);
+            }
+            __syncthreads();
+            double qx[PER], qy[PER], q2[PER];
+            int qs[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int64_t i = tid + (int64_t)u * HULL_BLOCK;
+                qs[u] = -1;
+                if (i < n) {
+                    qx[u] = px[i];
+                    qy[u] = py[i];
+                    const double dx = qx[u] - cx, dy = qy[u] - cy;
+                    q2[u] = dx * dx + dy * dy;
+                    qs[u] = sector_of(dx, dy, K);
+                    if (q2[u] < __longlong_as_double(0x7ff0000000000000ll))
+                        atomicMax(&fsect[qs[u]], (unsigned long long)__double_as_longlong(q2[u]) + 1ull);
+                }
+            }
+            __syncthreads();
+            if (tid < K && fsect[tid] == 0ull)
+                fdead = 1;                                 // an empty sector: nothing may be dropped
+            __syncthreads();
+            if (tid < K) {
+                const double c = cos(12.0 / (double)K);
+                const unsigned long long a = fsect[(tid + K - 1) % K], b = fsect[(tid + 1) % K];
+                const unsigned long long lo = a < b ? a : b;
+                fthr[tid] = fdead ? 0.0 : __longlong_as_double((long long)(lo - 1ull)) * ((c * c) * (1.0 - 1e-9));
+            }
+            __syncthreads();
+            // every thread holds its points in registers: the kept ones go back to the front of the arrays
+            // in any order (the sort follows)
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                if (qs[u] >= 0 && !(q2[u] < fthr[qs[u]])) {
+                    const int at = atomicAdd(&fcount, 1);
+                    px[at] = qx[u];
+                    py[at] = qy[u];
+                }
+            }
+            __syncthreads();
+            n = fcount;
+        }
+    }
     HULL_MARK(0);
 
     // ---- sort (ascending-only bitonic network, virtual +inf padding).  Strides are powers of two: the
@@ -640,6 +704,18 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
                                           void *stream)
 {
     PCFIT_ENTER();
+    return unique_hull_dev(x, y, offsets, n_slices, max_slice_len, ux, uy, n_unique, hull_idx, n_hull, status,
+                           hull_start, workspace, workspace_bytes, stream, 0);
+}
+
+// hull_only: the caller wants the hulls and no list of distinct points; slices of more than 1024 points then drop
+// their provably interior points before the sort, and ux / uy / n_unique describe what was kept (as they do for
+// slices beyond the LDS in any case); hull_start must be null.
+int pcfit::unique_hull_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                           int64_t max_slice_len, double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx,
+                           int64_t *n_hull, int32_t *status, const int64_t *hull_start, void *workspace,
+                           size_t workspace_bytes, void *stream, int hull_only)
+{
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "unique_hull: n_slices out of range");
     if (n_slices == 0)
         return PCFIT_OK;
@@ -692,11 +768,12 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
     PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&unique_hull_kernel<true, uint16_t>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, HULL_LDS_CAP * 18));
     unique_hull_kernel<true, uint16_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), lds, st>>>(
-        x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux);
+        x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux,
+        hull_only);
     PCFIT_LAUNCH_CHECK();
     if (max_slice_len > cap) {
         unique_hull_kernel<false, uint32_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), 0, st>>>(
-            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux);
+            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux, 0);
         PCFIT_LAUNCH_CHECK();
     }
     return PCFIT_OK;

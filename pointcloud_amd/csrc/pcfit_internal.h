@@ -15,6 +15,10 @@ namespace pcfit {
 
 void set_error(const char *fmt, ...);
 int bin_check_windows(const double *z_lo, const double *z_hi, int64_t n_slices, double geom[3]);   // bin.hip
+// hull.hip: pcfit_unique_hull_batch_dev with the option to drop interior points of medium slices too
+int unique_hull_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, int64_t max_slice_len,
+                    double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull, int32_t *status,
+                    const int64_t *hull_start, void *workspace, size_t workspace_bytes, void *stream, int hull_only);
 
 #define PCFIT_HIP(call)                                                                       \
     do {                                                                                      \

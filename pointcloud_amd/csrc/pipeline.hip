@@ -485,8 +485,10 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     int32_t *dst1 = reinterpret_cast<int32_t *>(d1.as<char>() + st1_at);
     if (hull_start) PCFIT_TRY(dhs.upload(hull_start, S * 8, st));
     PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, S)));
-    PCFIT_TRY(pcfit_unique_hull_batch_dev(dxp, dyp, doffp, S, max_len, dux.as<double>(), duy.as<double>(), dnu,
-                                          dhi.as<int64_t>(), dnh, dst1, dhs.as<int64_t>(), dws.p, dws.bytes, st));
+    // hull candidates and nobody asks for the distinct points: the hull kernel may drop interior points first
+    const int hull_only = (use_hull && !ux && !uy && !hull_start) ? 1 : 0;
+    PCFIT_TRY(unique_hull_dev(dxp, dyp, doffp, S, max_len, dux.as<double>(), duy.as<double>(), dnu, dhi.as<int64_t>(),
+                              dnh, dst1, dhs.as<int64_t>(), dws.p, dws.bytes, st, hull_only));
     hbuf.resize(d1_bytes);
     PCFIT_TRY(d1.download(hbuf.data(), d1_bytes, st));
     PCFIT_HIP(hipStreamSynchronize(st));

@@ -148,16 +148,18 @@ def hybrid_round(seed):
     restatement, with hull candidates and with all distinct points as candidates."""
     g = np.random.default_rng(seed)
     S = int(g.integers(2, 6))
-    sizes = [int(g.choice([0, 2, 3, 5, 40, 300, 1024, 2500, 6000])) for _ in range(S)]
+    sizes = [int(g.choice([0, 2, 3, 5, 40, 300, 1024, 1025, 2500, 6000, 8192])) for _ in range(S)]
     kinds, sets = zip(*(make_slice(g, n) for n in sizes))
     x = np.concatenate([s[:, 0] for s in sets]) if sum(sizes) else np.zeros(0)
     y = np.concatenate([s[:, 1] for s in sets]) if sum(sizes) else np.zeros(0)
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     use_hull = bool(g.random() < 0.7)
     trials = int(g.choice([50, 200]))
-    h = F.hybrid_batch(x, y, off, max_trials=trials, use_hull=use_hull, want_profile=False)
+    # (without the list of distinct points the hull kernel drops interior points before its sort)
+    want_unique = bool(g.random() < 0.4)
+    h = F.hybrid_batch(x, y, off, max_trials=trials, use_hull=use_hull, want_profile=False, want_unique=want_unique)
     for s, xy in enumerate(sets):
-        tag = f"[{kinds[s]} n={len(xy)} hull={use_hull}]"
+        tag = f"[{kinds[s]} n={len(xy)} hull={use_hull} unique={want_unique}]"
         if use_hull is False and len(xy) > 1024:
             continue                                      # (the restatement's RANSAC loop is too slow for these)
         ref = R.hybrid_fit(np.column_stack([xy, np.zeros(len(xy))]), 0.0, 1.0, max_trials=trials,

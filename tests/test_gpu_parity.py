@@ -661,8 +661,10 @@ def test_scan_level_call_matches_bin_then_hybrid():
     a = F.hybrid_batch(x, y, off, want_profile=True)
     b = F.scan_hybrid_batch(pts, zc - 1.0, zc + 1.0, want_profile=True)
     assert np.array_equal(off, b["offsets"])
-    for k in ("status", "n_unique", "cand_offsets", "cand_x", "cand_y", "mask", "radius", "theta", "argmax", "argmin"):
+    for k in ("status", "cand_offsets", "cand_x", "cand_y", "mask", "radius", "theta", "argmax", "argmin"):
         assert np.array_equal(a[k], b[k]), k
+    # (without the list of distinct points the hull kernel drops interior points first: fewer "unique" points)
+    assert np.all(b["n_unique"] <= a["n_unique"]) and np.all(b["n_unique"] >= np.diff(b["cand_offsets"]))
     assert np.array_equal(a["fit"], b["fit"], equal_nan=True)
     assert np.array_equal(a["ov"], b["ov"], equal_nan=True)
     K = min(a["grid_len"], b["grid_len"])
