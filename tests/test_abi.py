@@ -155,3 +155,27 @@ def test_csv_writers_match_the_reference_bytes(tmp_path):
     save_results(results, frames, str(tmp_path))
     assert (tmp_path / "slice_results.csv").read_bytes() == g["results_csv"].tobytes()
     assert (tmp_path / "slice_points.csv").read_bytes() == g["points_csv"].tobytes()
+
+
+def test_header_is_valid_c_and_links_against_the_library(tmp_path):
+    """include/pcfit.h compiles as C (gcc -std=c99 -pedantic) and a C program that takes the address of every
+    declared function links against libpcfit_hip.so: what a cgo / JNI / FFI binding of another language would do."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not found")
+    header = open(os.path.join(ROOT, "include", "pcfit.h")).read()
+    names = sorted(set(re.findall(r"\b(pcfit_[a-z0-9_]+)\s*\(", header)))
+    assert len(names) >= 40 and set(names) == set(F.SIGNATURES)
+    src = tmp_path / "link_all.c"
+    body = ",\n".join(f"    (fn){n}" for n in names)
+    src.write_text('#include "pcfit.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nstatic fn table[] = {\n' + body
+                   + '\n};\nint main(void)\n{\n    int live = 0;\n    unsigned k;\n'
+                     '    for (k = 0; k < sizeof table / sizeof table[0]; k++)\n        live += table[k] != 0;\n'
+                     '    printf("%d\\n", live);\n    return 0;\n}\n')
+    exe = tmp_path / "link_all"
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror",
+           "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe), F.SO_PATH,
+           "-Wl,--unresolved-symbols=ignore-in-shared-libs", "-Wl,-rpath," + os.path.dirname(F.SO_PATH)]
+    done = subprocess.run(cmd, capture_output=True, text=True)
+    assert done.returncode == 0, done.stderr
