@@ -45,6 +45,7 @@ FLOP_KASA = 18.0
 FLOP_SWEEP = 42.0
 FLOP_RESID = 45.0
 PEAK_FP64_VALU_TFLOPS = 78.6
+RING = 8                      # record buffers in flight between the fit kernel and the all-gather
 PEAK_HBM_GBS = 8000.0
 
 
@@ -98,6 +99,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # The fit kernels run on a stream of their own at normal priority and the process group's stream is asked for
+    # at high priority: HIP gives streams of different priorities different hardware queues. Two streams that land
+    # on one hardware queue run their work in submission order, and the gather of step i then sits in front of the
+    # fit kernel of step i+1 instead of beside it (seen in a kernel trace: 45 us between fit kernels, 20 us apart).
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
     dist = None
     # PCFIT_BENCH_FORCE_DIST=1 runs the collective path in a one-rank group (rehearsal on a one-GPU box)
     use_dist = world > 1 or os.environ.get("PCFIT_BENCH_FORCE_DIST") == "1"
@@ -106,7 +112,9 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
     L = F.lib()
 
     S, n, H = a.slices, a.points, a.bins
@@ -118,26 +126,36 @@ def main():
     off = torch.from_numpy(offh).to(dev)
     edges = torch.from_numpy(np.linspace(lo, hi, H + 1)).to(dev)
     kasa = torch.empty(S, 3, dtype=torch.float64, device=dev)
-    fit = [torch.empty(S, 3, dtype=torch.float64, device=dev) for _ in range(2)]
     hist = torch.empty(S, H, dtype=torch.int64, device=dev)
-    hist32 = [torch.empty(S, H, dtype=torch.int32, device=dev) for _ in range(2)]
+    # What travels between the ranks, one packed record per step: the S fitted circles (f64) followed by the
+    # S x H histogram counts. A count never exceeds the slice length, so 16 bits hold it for slices of up to
+    # 32767 points (half the bytes of int32 on the links). The fit kernel writes its circles straight into the
+    # record, so one collective per step carries everything and only the counts need a narrowing copy.
+    wire = torch.int16 if n <= 32767 else torch.int32
+    fit_bytes = S * 3 * 8
+    rec_bytes = fit_bytes + S * H * wire.itemsize
+    record = [torch.empty(rec_bytes, dtype=torch.uint8, device=dev) for _ in range(RING)]
+    fit = [r[:fit_bytes].view(torch.float64).view(S, 3) for r in record]
+    hist_wire = [r[fit_bytes:].view(wire).view(S, H) for r in record]
     iters = torch.empty(S, 4, dtype=torch.int32, device=dev)
     status = torch.empty(S, dtype=torch.int32, device=dev)
     rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
     amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
     if use_dist:
-        g_fit = [torch.empty(world * S, 3, dtype=torch.float64, device=dev) for _ in range(2)]
-        g_hist = [torch.empty(world * S, H, dtype=torch.int32, device=dev) for _ in range(2)]
-    pending = [None, None]
+        gathered = [torch.empty(world * rec_bytes, dtype=torch.uint8, device=dev) for _ in range(RING)]
+    pending = [None] * RING
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ev_k = []
 
     def step(i, timed):
-        b = i & 1
-        if pending[b] is not None:                  # buffers of step i-2 are still being gathered
-            for w in pending[b]:
+        b = i % RING
+        # Before a record buffer is written again its previous gather must have finished. Collectives complete in
+        # issue order, so one wait every RING/2 steps on the gather issued RING/2 steps ago covers the next RING/2
+        # buffers; a wait per step would put a cross-queue barrier in front of every fit kernel.
+        if b % (RING // 2) == 0:
+            w = pending[(b + RING // 2) % RING]
+            if w is not None:
                 w.wait()
-            pending[b] = None
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -148,15 +166,14 @@ def main():
         if timed:
             ev_k.append((e0, e1))
         if use_dist:
-            hist32[b].copy_(hist)
-            pending[b] = [dist.all_gather_into_tensor(g_fit[b], fit[b], async_op=True),
-                          dist.all_gather_into_tensor(g_hist[b], hist32[b], async_op=True)]
+            hist_wire[b].copy_(hist)
+            # (bytes on the wire: RCCL has no 16-bit integer type)
+            pending[b] = dist.all_gather_into_tensor(gathered[b], record[b], async_op=True)
 
     def drain():
-        for b in (0, 1):
+        for b in range(RING):
             if pending[b] is not None:
-                for w in pending[b]:
-                    w.wait()
+                pending[b].wait()
                 pending[b] = None
 
     for i in range(a.warmup):
@@ -169,12 +186,15 @@ def main():
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i, True)
+    t_host = time.perf_counter() - t0
     drain()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if os.environ.get("PCFIT_BENCH_DEBUG") == "1":
+        print(f"[bench] host enqueue {t_host / a.steps * 1e3:.3f} ms/step of {dt / a.steps * 1e3:.3f}", file=sys.stderr)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

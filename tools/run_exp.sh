@@ -1,9 +1,7 @@
-# scratch driver for timing experiments on the GPU box
-set -e
-cd $GRAFT_REPO_ROOT
-for S in 57 200 2000; do
-    echo "== S=$S default stores"
-    C4N=50000000 C4S=$S timeout -k 10 120 python3 -u tools/exp_all.py c4 2>&1 | grep -E "bin scatter"
-    echo "== S=$S non-temporal loads"
-    PCFIT_SO=libpcfit_hip_nt.so C4N=50000000 C4S=$S timeout -k 10 120 python3 -u tools/exp_all.py c4 2>&1 | grep -E "bin scatter"
+#!/bin/bash
+# scratch: bench with and without the exchange, one rank
+mkdir -p gpurun_out
+for m in 0 1; do
+  echo "== force_dist=$m"
+  PCFIT_BENCH_DEBUG=1 PCFIT_BENCH_FORCE_DIST=$m timeout -k 10 200 python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpurun_out/ex_$m.json 2> gpurun_out/ex_$m.err || { tail -5 gpurun_out/ex_$m.err; exit 1; }; grep "\[bench\]" gpurun_out/ex_$m.err
 done
