@@ -318,6 +318,225 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
     }
 }
 
+// Scatter through LDS for up to BIN_STG_MAX_SLICES windows.  The direct scatter above stores 8 bytes at a
+// time at up to 64 unrelated addresses per trip; when consecutive points fall in unrelated windows the
+// memory system sees partial lines (measured: 2.9 bytes written to HBM per byte of output).  Here a
+// workgroup of four waves takes its chunk in tiles of TILE points, orders each tile by window inside LDS
+// (same order as the input within a window) and copies the ordered tile out, so that neighbouring lanes
+// store neighbouring addresses: a tile's members of one window are one contiguous run of the output.
+//
+//   pass 1   wave w walks its quarter of the tile, 64 points a trip: window of every point, its rank
+//            among the wave's members of that window (ballots, as above), count per (wave, window);
+//   scan     per window: members in the tile, first LDS slot of the window's run, first slot of every
+//            wave's share of the run, and where the run goes in the output;
+//   pass 2   every point into its slot; pass 3: the slots, in order, to the output.
+//
+// A tile whose members (points on a shared edge count twice) exceed the staging area is stored directly
+// from pass 2 with the same positions.
+constexpr int BIN_STG_MAX_SLICES = 256;      // window index fits the byte kept per staged point
+
+template <int TILE> constexpr int bin_stage_cap() { return TILE + TILE / 16; }
+
+template <int TILE, int WAVES, bool PERM> static size_t bin_stage_lds(int64_t S)
+{
+    const size_t cap = (size_t)bin_stage_cap<TILE>();
+    return cap * 16 + (size_t)S * 16 + ((size_t)WAVES * S + (size_t)S + 1 + WAVES) * 4 +
+           (PERM ? cap * 4 : 0) + cap;
+}
+
+template <int NBITS, bool PERM, int TILE, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
+    const double *__restrict__ xyz, int64_t n, int64_t chunk_len, const double *__restrict__ z_lo,
+    const double *__restrict__ z_hi, BinGeom g, const uint32_t *__restrict__ counts,
+    const int64_t *__restrict__ segbase, const int64_t *__restrict__ offsets, double *__restrict__ x_out,
+    double *__restrict__ y_out, int64_t *__restrict__ perm)
+{
+    constexpr int TRIPS = TILE / (64 * WAVES);
+    constexpr int CAP = bin_stage_cap<TILE>();
+    extern __shared__ __align__(16) unsigned char stg_lds[];
+    const int S = (int)g.S;
+    double2 *stage = reinterpret_cast<double2 *>(stg_lds);
+    int64_t *gpos = reinterpret_cast<int64_t *>(stg_lds + (size_t)CAP * 16);   // next output slot per window
+    int64_t *gdelta = gpos + S;                                                  // output slot - LDS slot
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(gdelta + S);                    // [wave][window]
+    uint32_t *lstart = cnt + WAVES * S;                                  // S + 1
+    uint32_t *wave_sum = lstart + S + 1;                                         // WAVES
+    uint32_t *sidx = wave_sum + WAVES;                                   // CAP, with PERM
+    uint8_t *skey = reinterpret_cast<uint8_t *>(sidx + (PERM ? CAP : 0));        // CAP
+
+    const int64_t c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t *cw = cnt + w * S;
+    for (int s = tid; s < S; s += 64 * WAVES)
+        gpos[s] = offsets[s] + segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s];
+    const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
+    for (int64_t tbase = begin; tbase < end; tbase += TILE) {
+        for (int s = tid; s < WAVES * S; s += 64 * WAVES)
+            cnt[s] = 0;
+        __syncthreads();
+        // pass 1
+        double px[TRIPS], py[TRIPS];
+        uint32_t key[TRIPS], r1[TRIPS], r2[TRIPS];      // key: window + 1, bit 31 = also in the next window
+        const int64_t wbase = tbase + (int64_t)w * (TRIPS * 64);
+        {
+            // every load of the tile is issued before the first is used; lanes past the end read the
+            // chunk's last point and get NaN for z: no window
+            double pz[TRIPS];
+#pragma unroll
+            for (int u = 0; u < TRIPS; u++) {
+                const int64_t i = wbase + 64 * u + lane;
+                const int64_t ic = i < end ? i : end - 1;
+                px[u] = xyz[3 * ic];
+                py[u] = xyz[3 * ic + 1];
+                pz[u] = xyz[3 * ic + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < TRIPS; u++) {
+                const int64_t i = wbase + 64 * u + lane;
+                int32_t k1;
+                bool has2;
+                windows_of(i < end ? pz[u] : __longlong_as_double(0x7ff8000000000000ll), g, z_lo, z_hi, k1, has2);
+                key[u] = (uint32_t)(k1 + 1) | (has2 ? 0x80000000u : 0u);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const bool has2 = (key[u] >> 31) != 0u;
+            const int32_t k1 = (int32_t)(key[u] & 0x7fffffffu) - 1;
+            const uint32_t k = (uint32_t)(k1 + 1);
+            uint64_t bit_ballot[NBITS];
+            key_ballots<NBITS>(k, bit_ballot);
+            const uint64_t twice = __ballot(has2);
+            const uint64_t same = match_lanes<NBITS>(bit_ballot, k);
+            uint32_t a1 = 0, a2 = 0;
+            if (twice == 0ull) {
+                if (k1 >= 0) {
+                    const int rank = __popcll(same & below), m = __popcll(same);
+                    const uint32_t rel = cw[k1];
+                    if (rank == m - 1)
+                        cw[k1] = rel + m;
+                    a1 = rel + rank;
+                }
+            } else {
+                const uint64_t from_prev = match_lanes<NBITS>(bit_ballot, k - 1u) & twice;
+                const uint64_t to_next = match_lanes<NBITS>(bit_ballot, k + 1u);
+                int rank1 = 0, m1 = 0, rank2 = 0, m2 = 0;
+                uint32_t rel1 = 0, rel2 = 0;
+                if (k1 >= 0) {
+                    const uint64_t grp1 = same | (k >= 2u ? from_prev : 0ull);
+                    rank1 = __popcll(grp1 & below);
+                    m1 = __popcll(grp1);
+                    rel1 = cw[k1];
+                    if (has2) {
+                        const uint64_t grp2 = to_next | (same & twice);
+                        rank2 = __popcll(grp2 & below);
+                        m2 = __popcll(grp2);
+                        rel2 = cw[k1 + 1];
+                    }
+                }
+                // all reads of the counts precede the writes (one wave, LDS ops in order)
+                if (k1 >= 0) {
+                    if (rank1 == m1 - 1)
+                        cw[k1] = rel1 + m1;
+                    if (has2 && rank2 == m2 - 1)
+                        cw[k1 + 1] = rel2 + m2;
+                    a1 = rel1 + rank1;
+                    a2 = rel2 + rank2;
+                }
+            }
+            r1[u] = a1;
+            r2[u] = a2;
+        }
+        __syncthreads();
+        // scan: thread s owns window s
+        uint32_t part[WAVES], tot = 0;
+        if (tid < S) {
+#pragma unroll
+            for (int j = 0; j < WAVES; j++) {
+                part[j] = cnt[j * S + tid];
+                tot += part[j];
+            }
+        }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        if (lane == 63)
+            wave_sum[w] = incl;
+        __syncthreads();
+        uint32_t before = 0, tile_total = 0;
+#pragma unroll
+        for (int j = 0; j < WAVES; j++) {
+            const uint32_t t = wave_sum[j];
+            before += j < w ? t : 0u;
+            tile_total += t;
+        }
+        if (tid < S) {
+            uint32_t first = before + incl - tot;
+            lstart[tid] = first;
+            const int64_t gp = gpos[tid];
+            gdelta[tid] = gp - (int64_t)first;
+            gpos[tid] = gp + (int64_t)tot;
+#pragma unroll
+            for (int j = 0; j < WAVES; j++) {
+                cnt[j * S + tid] = first;
+                first += part[j];
+            }
+        }
+        __syncthreads();
+        const bool direct = tile_total > (uint32_t)CAP;         // (uniform over the workgroup)
+        // pass 2
+#pragma unroll
+        for (int u = 0; u < TRIPS; u++) {
+            const uint32_t k = key[u] & 0x7fffffffu;
+            if (k == 0u)
+                continue;
+            const int k1 = (int)k - 1;
+            const bool has2 = (key[u] >> 31) != 0u;
+            const uint32_t local = (uint32_t)(w * (TRIPS * 64) + 64 * u + lane);
+            const uint32_t p1 = cw[k1] + r1[u];
+            const uint32_t p2 = has2 ? cw[k1 + 1] + r2[u] : 0u;
+            if (!direct) {
+                stage[p1] = make_double2(px[u], py[u]);
+                skey[p1] = (uint8_t)k1;
+                if (PERM) sidx[p1] = local;
+                if (has2) {
+                    stage[p2] = make_double2(px[u], py[u]);
+                    skey[p2] = (uint8_t)(k1 + 1);
+                    if (PERM) sidx[p2] = local;
+                }
+            } else {
+                const int64_t d1 = gdelta[k1] + (int64_t)p1;
+                x_out[d1] = px[u];
+                y_out[d1] = py[u];
+                if (PERM) perm[d1] = tbase + local;
+                if (has2) {
+                    const int64_t d2 = gdelta[k1 + 1] + (int64_t)p2;
+                    x_out[d2] = px[u];
+                    y_out[d2] = py[u];
+                    if (PERM) perm[d2] = tbase + local;
+                }
+            }
+        }
+        __syncthreads();
+        // pass 3
+        if (!direct) {
+            for (uint32_t e = tid; e < tile_total; e += 64 * WAVES) {
+                const double2 v = stage[e];
+                const int64_t d = gdelta[skey[e]] + (int64_t)e;
+                x_out[d] = v.x;
+                y_out[d] = v.y;
+                if (PERM) perm[d] = tbase + sidx[e];
+            }
+        }
+        // (the next tile's first barrier comes before anything read in pass 3 is written again)
+    }
+}
+
 // the kernels take the number of key bits as a template argument: the next size up of a few
 template <int N> struct KeyBits { static constexpr int value = N; };
 template <class F> static void with_key_bits(int nbits, F &&f)
@@ -460,6 +679,35 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     int nbits = 1;
     while ((1ll << nbits) < n_slices + 2)
         nbits++;
+    static const int staged = [] { const char *e = getenv("PCFIT_BIN_STAGED"); return e ? atoi(e) : 1; }();
+    if (staged && n_slices <= BIN_STG_MAX_SLICES) {
+        int rc2 = PCFIT_OK;
+        with_key_bits(nbits, [&](auto tag) {
+            constexpr int NB = decltype(tag)::value < 10 ? decltype(tag)::value : 10;    // 258 keys at most
+            auto launch = [&](auto kern, size_t lds, int waves) {
+                // more than 64 KB of dynamic LDS has to be granted explicitly (per device; idempotent)
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                    (void)hipGetLastError();
+                    set_error("bin: %zu bytes of LDS refused", lds);
+                    rc2 = PCFIT_ERR_HIP;
+                    return;
+                }
+                kern<<<dim3((unsigned)p.chunks), dim3(64 * waves), lds, st>>>(
+                    xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+            };
+            // Tiles of 2048 points on four waves. Measured against 4096 x 4 and 4096 x 8: longer tiles make
+            // longer runs (50 M points in random order, 57 windows, no perm: 0.47 vs 0.56 ms) but leave one or two
+            // workgroups per CU, which loses more wherever the input is partly ordered, small, or perm is wanted.
+            if (perm)
+                launch(&bin_scatter_staged_kernel<NB, true, 2048, 4>, bin_stage_lds<2048, 4, true>(n_slices), 4);
+            else
+                launch(&bin_scatter_staged_kernel<NB, false, 2048, 4>, bin_stage_lds<2048, 4, false>(n_slices), 4);
+        });
+        if (rc2) return rc2;
+        PCFIT_LAUNCH_CHECK();
+        return PCFIT_OK;
+    }
     with_key_bits(nbits, [&](auto tag) {
         constexpr int NB = decltype(tag)::value;
         if (perm)

@@ -1,7 +1,7 @@
 #!/bin/bash
-# scratch: bench with and without the exchange, one rank
+# scratch: staged scatter checks
 mkdir -p gpurun_out
-for m in 0 1; do
-  echo "== force_dist=$m"
-  PCFIT_BENCH_DEBUG=1 PCFIT_BENCH_FORCE_DIST=$m timeout -k 10 200 python3 bench.py --steps 30 --warmup 3 --no-cpu-baseline > gpurun_out/ex_$m.json 2> gpurun_out/ex_$m.err || { tail -5 gpurun_out/ex_$m.err; exit 1; }; grep "\[bench\]" gpurun_out/ex_$m.err
-done
+timeout -k 10 600 python3 -u tests/fuzz_parity.py 300 7000 > gpurun_out/fuzz_bin.txt 2>&1 || { tail -20 gpurun_out/fuzz_bin.txt; exit 1; }
+tail -2 gpurun_out/fuzz_bin.txt
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -30 gpurun_out/gpu_tests.txt; exit 1; }
+tail -3 gpurun_out/gpu_tests.txt
