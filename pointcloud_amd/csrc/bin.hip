@@ -12,7 +12,9 @@
 //            bits, so a lane's rank among its peers and the peer count are bit
 //            counts; one LDS cursor per window (private to the wave, seeded from
 //            the scan) gives the output position.  No atomics, no inter-wave
-//            ordering: stable and deterministic by construction.
+//            ordering: stable and deterministic by construction.  For up to
+//            256 windows the points go through LDS first (see
+//            bin_scatter_staged_kernel) so that the output is written in runs.
 //
 // Windows are closed intervals that may share an edge, so a point can belong
 // to two consecutive windows (both get a copy) or to none.  Membership is
