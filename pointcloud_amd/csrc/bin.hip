@@ -129,20 +129,29 @@ __global__ void bin_segsum_kernel(const uint32_t *__restrict__ counts, int64_t c
     segsum[seg * S + s] = acc;
 }
 
-// per window: exclusive prefix of the segment sums (in place) and the total
-__global__ void bin_segscan_kernel(int64_t *__restrict__ segsum, int64_t segs, int64_t S,
-                                   int64_t *__restrict__ totals)
+// per window: exclusive prefix of the segment sums (in place) and the total; one wave per window, 64 segments a step
+__global__ __launch_bounds__(64) void bin_segscan_kernel(int64_t *__restrict__ segsum, int64_t segs, int64_t S,
+                                                        int64_t *__restrict__ totals)
 {
-    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (s >= S)
-        return;
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
     int64_t run = 0;
-    for (int64_t g = 0; g < segs; g++) {
-        const int64_t t = segsum[g * S + s];
-        segsum[g * S + s] = run;
-        run += t;
+    for (int64_t base = 0; base < segs; base += 64) {
+        const int64_t sg = base + lane;
+        const int64_t v = sg < segs ? segsum[sg * S + s] : 0;
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        if (sg < segs)
+            segsum[sg * S + s] = run + incl - v;
+        run += __shfl(incl, 63);
     }
-    totals[s] = run;
+    if (lane == 0)
+        totals[s] = run;
 }
 
 // offsets[0..S] = exclusive prefix of totals; one workgroup, serial over tiles of 1024
@@ -648,7 +657,7 @@ PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const dou
     const dim3 cols((unsigned)((S + 255) / 256), (unsigned)p.segs);
     bin_segsum_kernel<<<cols, dim3(256), 0, st>>>(counts, p.chunks, S, segsum);
     PCFIT_LAUNCH_CHECK();
-    bin_segscan_kernel<<<dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st>>>(segsum, p.segs, S, totals);
+    bin_segscan_kernel<<<dim3((unsigned)S), dim3(64), 0, st>>>(segsum, p.segs, S, totals);
     PCFIT_LAUNCH_CHECK();
     bin_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(totals, S, offsets);
     PCFIT_LAUNCH_CHECK();
