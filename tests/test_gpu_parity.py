@@ -649,6 +649,13 @@ def test_scan_sized_boundary_and_histogram_pass():
         o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
         assert np.array_equal(o["hist"], res["hist"][s])
         assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
+    # the same scan in 200 windows of twice the width: up to 256 windows the scatter orders its tiles in LDS
+    lo2, hi2 = lo[0::2], hi[1::2]
+    off2, x2, y2, perm2 = F.bin_slices(pts, lo2, hi2)
+    assert off2[-1] == np.count_nonzero((z >= lo2[0]) & (z <= hi2[-1])) + np.count_nonzero(np.isin(z, lo2[1:]))
+    assert np.array_equal(x2, pts[perm2, 0]) and np.array_equal(y2, pts[perm2, 1])
+    for s in (0, 77, 199):
+        assert np.array_equal(perm2[off2[s]:off2[s + 1]], R.slice_members(z, lo2[s], hi2[s]))
 
 
 def test_scan_level_call_matches_bin_then_hybrid():
