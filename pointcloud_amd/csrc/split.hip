@@ -21,6 +21,8 @@
 #include <algorithm>
 
 #include "fit_math.h"
+#include <stdlib.h>
+
 #include "pcfit_internal.h"
 #include "segments.h"
 
@@ -518,12 +520,74 @@ int split_lm(const double *x, const double *y, const int64_t *offsets, int64_t S
     PCFIT_HIP(hipMemsetAsync(active, 0, 8, st));
     split_lm_init_kernel<<<dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st>>>(offsets, S, init, prm, w.slices, out,
                                                                                    iters, skip_status, active);
-    // one first sweep and at most max_iter candidate sweeps; finished slices cost a few loads per workgroup
-    for (int32_t round = 0; round <= prm.max_iter; round++) {
-        split_part_kernel<2><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, S, w.segstart, w.slices, prm, w.part);
-        split_lm_step_kernel<<<dim3((unsigned)S), dim3(WAVE), 0, st>>>(w.segstart, w.part, prm, w.slices, out, iters,
-                                                                       active);
+    // One first sweep and at most max_iter candidate sweeps; once every slice has finished a round is two launches
+    // that return at once. The rounds go out in batches of LM_BATCH. After each batch the number of unfinished
+    // slices is copied to pinned host memory, and before batch k is enqueued the host looks at the count left by
+    // batch k-2 (batch k-1 keeps the GPU busy meanwhile): zero ends the loop, so at most two batches of idle rounds
+    // are launched instead of max_iter minus the rounds needed (typically 100 minus 10-25; about 8 us a round).
+    // Under stream capture nothing can be read back, and every round is enqueued.
+    constexpr int32_t LM_BATCH = 8;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
     }
+    static const int allowed = [] { const char *e = getenv("PCFIT_LM_ADAPTIVE"); return e ? atoi(e) : 1; }();
+    const bool adaptive = allowed && cap == hipStreamCaptureStatusNone && prm.max_iter + 1 > 3 * LM_BATCH;
+    int64_t *seen = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (adaptive) {
+        static thread_local int64_t *pinned = nullptr;               // two counters, kept for the thread's life
+        if (!pinned)
+            PCFIT_HIP(hipHostMalloc(reinterpret_cast<void **>(&pinned), 2 * sizeof(int64_t), hipHostMallocPortable));
+        seen = pinned;
+        PCFIT_HIP(hipEventCreateWithFlags(&ev[0], hipEventDisableTiming));
+        const hipError_t e1 = hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+        if (e1 != hipSuccess) {
+            (void)hipEventDestroy(ev[0]);
+            PCFIT_HIP(e1);
+        }
+    }
+    int rc = PCFIT_OK;
+    int32_t round = 0;
+    int batch = 0;
+    for (; round <= prm.max_iter && rc == PCFIT_OK; batch++) {
+        if (adaptive && batch >= 2) {
+            if (hipEventSynchronize(ev[batch & 1]) != hipSuccess) {
+                set_error("lm_split: waiting for a batch of rounds failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = PCFIT_ERR_HIP;
+                break;
+            }
+            if (seen[batch & 1] == 0)
+                break;
+        }
+        const int32_t last = adaptive ? std::min<int32_t>(prm.max_iter, round + LM_BATCH - 1) : prm.max_iter;
+        for (; round <= last; round++) {
+            split_part_kernel<2><<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, S, w.segstart, w.slices, prm,
+                                                                     w.part);
+            split_lm_step_kernel<<<dim3((unsigned)S), dim3(WAVE), 0, st>>>(w.segstart, w.part, prm, w.slices, out,
+                                                                           iters, active);
+        }
+        if (adaptive && (hipMemcpyAsync(&seen[batch & 1], active, sizeof(int64_t), hipMemcpyDeviceToHost, st) !=
+                             hipSuccess ||
+                         hipEventRecord(ev[batch & 1], st) != hipSuccess)) {
+            set_error("lm_split: reading the count of unfinished slices failed: %s",
+                      hipGetErrorString(hipGetLastError()));
+            rc = PCFIT_ERR_HIP;
+        }
+    }
+    if (adaptive) {
+        // the counters belong to the thread, not to the call: the last copy into them has to land before another
+        // call may use them (what is still queued by then is at most one batch of rounds)
+        if (batch > 0 && hipEventSynchronize(ev[(batch - 1) & 1]) != hipSuccess && rc == PCFIT_OK) {
+            set_error("lm_split: waiting for the last batch of rounds failed: %s",
+                      hipGetErrorString(hipGetLastError()));
+            rc = PCFIT_ERR_HIP;
+        }
+        (void)hipEventDestroy(ev[0]);
+        (void)hipEventDestroy(ev[1]);
+    }
+    if (rc) return rc;
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }

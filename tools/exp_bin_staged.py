@@ -44,7 +44,10 @@ def run(N, S, mode, want_perm):
           f"{(N * 24 + tot * (24 if want_perm else 16)) / ms / 1e6:8.1f} GB/s  {h.hexdigest()[:12]}", flush=True)
 
 
-for N, S in ((50_000_000, 57), (20_000_000, 200), (1_000_000, 57), (100_003, 7), (5_000_000, 256)):
+CASES = ((50_000_000, 57), (20_000_000, 200), (1_000_000, 57), (100_003, 7), (5_000_000, 256))
+if len(sys.argv) > 2:
+    CASES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for N, S in CASES:
     for mode in ("random", "sorted", "edges"):
         for want_perm in (False, True):
             run(N, S, mode, want_perm)
