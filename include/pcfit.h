@@ -146,8 +146,13 @@ int pcfit_fit_residuals_batch_dev(const double *x, const double *y, const int64_
  * to rounding (~1e-15), integer results exactly.  total_points = offsets[n_slices].
  * workspace: pcfit_split_workspace_bytes(total_points, n_slices, bins) bytes of
  * device memory (bins = 0 unless pcfit_angle_max_split_dev is called).
- * pcfit_lm_split_dev enqueues max_iter + 1 rounds of two launches; slices that
- * have finished cost next to nothing in the later rounds. */
+ * pcfit_lm_split_dev / pcfit_fit_split_dev run at most max_iter + 1 rounds of
+ * two launches.  The rounds are enqueued eight at a time and the calling thread
+ * reads back, two batches late, how many slices are unfinished, so these two
+ * calls return only when the rounds they enqueued have run (unlike the other
+ * *_dev calls).  On a stream that is being captured nothing is read back and
+ * all max_iter + 1 rounds are enqueued; finished slices cost next to nothing
+ * in the later rounds. */
 size_t pcfit_split_workspace_bytes(int64_t total_points, int64_t n_slices, int32_t n_bins);
 int pcfit_kasa_split_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                          int64_t total_points, double *cxcyr, int32_t *status, void *workspace,

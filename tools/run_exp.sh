@@ -1,6 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out
-C4N=50000000 C4S=57 timeout -k 10 300 python3 tools/exp_all.py c4 2>&1 | grep "split kasa+lm\|sweeps" || exit 1
-timeout -k 10 300 python3 tools/exp_analyzer.py 2>&1 | tail -12 || exit 1
-timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -30 gpurun_out/gpu_tests.txt; exit 1; }
-tail -3 gpurun_out/gpu_tests.txt
+for a in 0 1; do
+echo "PCFIT_LM_ADAPTIVE=$a"
+PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 2>&1 | tail -1 || exit 1
+PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 20000000 57 2>&1 | tail -1 || exit 1
+PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 50000000 200 2>&1 | tail -1 || exit 1
+done
