@@ -1,7 +1,8 @@
 #!/bin/bash
-for a in 0 1; do
-echo "PCFIT_LM_ADAPTIVE=$a"
-PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 2>&1 | tail -1 || exit 1
-PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 20000000 57 2>&1 | tail -1 || exit 1
-PCFIT_LM_ADAPTIVE=$a timeout -k 10 300 python3 tools/exp_resident.py 50000000 200 2>&1 | tail -1 || exit 1
-done
+set -e
+R=$GRAFT_REPO_ROOT
+mkdir -p $R/gpurun_out/r01g
+timeout -k 10 400 python3 $R/bench.py > $R/gpurun_out/r01g/bench.json 2> $R/gpurun_out/r01g/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r01g/trace -o b --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/r01g/bench_prof.log 2>&1
+cat $R/gpurun_out/r01g/bench.json
