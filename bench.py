@@ -220,6 +220,10 @@ def main():
             ("fit_kernel (Kasa + LM)", lambda: F.check(L.pcfit_fit_batch_dev(
                 ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit[0]), ptr(iters),
                 ptr(status), stream))),
+            ("fit_residual_kernel with max_iter = 0 (Kasa + residual pass, one read of the slice)",
+             lambda: F.check(L.pcfit_fit_residuals_batch_dev(
+                 ptr(x), ptr(y), ptr(off), S, n, 1.0, 0, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit[0]), ptr(iters),
+                 ptr(status), H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream))),
             ("residuals_kernel (histogram + extremes)", lambda: F.check(L.pcfit_residuals_batch_dev(
                 ptr(x), ptr(y), ptr(off), S, ptr(fit[0]), None, None, None, H, ptr(edges), ptr(hist), ptr(rmm),
                 ptr(amm), stream))),
