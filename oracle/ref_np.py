@@ -394,6 +394,24 @@ def residual_profile(xy, cx, cy, rad):
     return theta[order], (r - rad)[order]
 
 
+def filtered_residual_profile(xy, cx, cy, rad, inlier_mask=None):
+    """gui.py:1626-1655 without the plotting: delta_r of the edge points filtered by the inlier mask (when it has
+    one entry per point) or by the 95 % quantile of |delta_r|, ordered by theta, theta in degrees."""
+    xy = np.asarray(xy, float)
+    dx = xy[:, 0] - cx
+    dy = xy[:, 1] - cy
+    theta = (np.arctan2(dy, dx) + 2 * np.pi) % (2 * np.pi)
+    delta_r = np.hypot(dx, dy) - rad
+    if inlier_mask is not None and len(inlier_mask) == len(xy):
+        valid = np.asarray(inlier_mask, bool)
+    else:
+        mag = np.abs(delta_r)
+        valid = mag <= np.quantile(mag, 0.95)
+    theta, delta_r = theta[valid], delta_r[valid]
+    order = np.argsort(theta)
+    return np.degrees(theta[order]), delta_r[order], valid
+
+
 def residual_histogram(delta_r, bins, lo, hi):
     """Counts of delta_r over ``bins`` equal bins on [lo, hi]: half-open bins,
     last bin closed, values outside dropped (numpy.histogram semantics).  Not in

@@ -30,6 +30,25 @@ def compute_residual_profile(result):
     return residual_profile(np.array(result["boundary_points"]), result["cx"], result["cy"], result["R"])
 
 
+def filtered_residual_profile(points_xy, cx, cy, R, inlier_mask=None, quantile=0.95):
+    """The profile the slice view draws (gui.py:1626-1655, data part): delta_r of the edge points, kept where
+    ``inlier_mask`` says so when it has one entry per point, otherwise where |delta_r| is at most its
+    ``quantile`` quantile; ordered by theta, theta in degrees.  Returns (theta_deg, delta_r, kept) with
+    ``kept`` the boolean mask over the input points."""
+    xy = np.asarray(points_xy, float).reshape(-1, 2)
+    if len(xy) == 0:
+        return np.zeros(0), np.zeros(0), np.zeros(0, bool)
+    theta, dr = residual_profile(xy, cx, cy, R, sort=False)
+    if inlier_mask is not None and len(inlier_mask) == len(xy):
+        kept = np.asarray(inlier_mask, bool)
+    else:
+        mag = np.abs(dr)
+        kept = mag <= np.quantile(mag, quantile)
+    theta, dr = theta[kept], dr[kept]
+    order = np.argsort(theta)
+    return np.degrees(theta[order]), dr[order], kept
+
+
 def residual_histogram(points_xy, cx, cy, R, bins, lo, hi):
     """numpy.histogram(delta_r, bins=bins, range=(lo, hi)) computed on the GPU."""
     xy = np.asarray(points_xy, float).reshape(-1, 2)

@@ -145,6 +145,23 @@ def test_boundary_golden():
         th, dr = RS.residual_profile(xy, *fit)
         assert np.max(np.abs(th - g[f"rp_theta{i}"])) <= THETA_ABS
         assert np.max(np.abs(dr - g[f"rp_dr{i}"])) <= 2 * np.spacing(fit[2])
+        # the slice view's filtered profile (gui.py:1626-1655): by inlier mask, then by the 95 % quantile of |dr|
+        mask = np.random.default_rng(i).random(len(xy)) < 0.8
+        for m in (mask, None, mask[:-1]):                            # a mask of the wrong length is ignored
+            td, dd, kept = RS.filtered_residual_profile(xy, *fit, inlier_mask=m)
+            td_o, dd_o, kept_o = R.filtered_residual_profile(xy, *fit, inlier_mask=m)
+            if m is None or len(m) != len(xy):
+                # a point whose |dr| sits within rounding of the quantile may fall on either side
+                mag = np.abs(R.polar(np.asarray(xy, float), fit[0], fit[1])[1] - fit[2])
+                edge = np.abs(mag - np.quantile(mag, 0.95)) <= 4 * np.spacing(fit[2])
+                assert np.array_equal(kept[~edge], kept_o[~edge])
+                if edge.any():
+                    continue
+            assert np.array_equal(kept, kept_o)
+            # (the conversion to degrees rounds once more on either side)
+            assert np.max(np.abs(td - td_o), initial=0.0) <= np.degrees(THETA_ABS) + np.spacing(360.0)
+            assert np.max(np.abs(dd - dd_o), initial=0.0) <= 2 * np.spacing(fit[2])
+    assert RS.filtered_residual_profile(np.zeros((0, 2)), 0.0, 0.0, 1.0)[0].size == 0
 
 
 # ------------------------------------------------------------------ against the C restatement

@@ -188,3 +188,18 @@ def test_process_slice_edge_frame_and_skip():
     assert same_cycle(list(zip(edge["x"], edge["y"])), ref_xy)
     _, _, msg = R.process_slice(pts[:500], zc[3])
     assert msg == str(g["ps_sparse_msg"])
+
+
+def test_filtered_residual_profile_rules():
+    """gui.py:1626-1655: inlier mask when it fits, else the 95 % quantile of |delta_r|; theta ascending, in degrees."""
+    g = np.random.default_rng(5)
+    th = g.uniform(0, 2 * np.pi, 400)
+    r = 10.0 + g.normal(0, 0.05, 400)
+    r[::37] += 3.0                                             # gross outliers
+    xy = np.stack([3.0 + r * np.cos(th), -2.0 + r * np.sin(th)], 1)
+    mask = g.random(400) < 0.7
+    td, dr, kept = R.filtered_residual_profile(xy, 3.0, -2.0, 10.0, inlier_mask=mask)
+    assert np.array_equal(kept, mask) and len(td) == mask.sum() and np.all(np.diff(td) >= 0) and td.max() < 360.0
+    td, dr, kept = R.filtered_residual_profile(xy, 3.0, -2.0, 10.0, inlier_mask=mask[:-1])
+    assert kept.sum() == 380 and np.abs(dr).max() < 1.0       # the outliers are gone
+    assert np.allclose(np.sort(np.degrees(th[kept])), td)
