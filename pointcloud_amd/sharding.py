@@ -103,3 +103,60 @@ def analyze_sharded(analyzer, points, group=None, progress_callback=None):
     if progress_callback:
         progress_callback(100)
     return results
+
+
+def scans_of_rank(n_scans: int, rank: int, world: int):
+    """Whole scans go to the ranks round-robin: rank r analyses scans r, r + world, ..."""
+    return list(range(rank, n_scans, world))
+
+
+def analyze_scans_sharded(analyzer, scans, group=None, progress_callback=None, gather=True):
+    """A batch of independent scans over the ranks of ``group``: whole scans round-robin to the ranks (no cuts
+    through a scan, no exchange of points), each rank running its scans one after the other with the upload of
+    the next one (a second host thread making the DeviceScan) overlapped with the analysis of the current one.
+    ``scans``: a sequence whose items are (N, 3) arrays or callables returning one (so that a rank only loads
+    what it analyses).  Returns the list of per-scan result lists, in the order of ``scans``; entries of other
+    ranks are filled in when ``gather`` (all_gather_object of the result dicts), else left as None.
+    Without an initialised process group the one caller takes every scan."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from ._ffi import DeviceScan
+
+    world, rank = 1, 0
+    dist = None
+    try:
+        import torch.distributed as dist_mod
+        if dist_mod.is_available() and dist_mod.is_initialized():
+            dist = dist_mod
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+    except ImportError:
+        pass
+    mine = scans_of_rank(len(scans), rank, world)
+
+    def resident(k):
+        item = scans[k]
+        pts = item() if callable(item) else item
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("Points must be Nx3 array")
+        return DeviceScan(pts)
+
+    out = [None] * len(scans)
+    with ThreadPoolExecutor(1) as pool:
+        nxt = pool.submit(resident, mine[0]) if mine else None
+        for j, k in enumerate(mine):
+            cur = nxt.result()
+            nxt = pool.submit(resident, mine[j + 1]) if j + 1 < len(mine) else None
+            try:
+                out[k] = analyzer.analyze_with_progress(cur)
+            finally:
+                cur.close()
+            if progress_callback:
+                progress_callback(int(100 * (j + 1) / len(mine)))
+    if dist is not None and gather and world > 1:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, {k: out[k] for k in mine}, group=group)
+        for part in everyone:
+            for k, res in part.items():
+                out[k] = res
+    return out

@@ -40,6 +40,24 @@ def main():
             for a, b in zip(res, single):
                 ok &= a["z_center"] == b["z_center"] and a["cx"] == b["cx"] and a["R"] == b["R"]
                 ok &= a["boundary_points"] == b["boundary_points"] and a["n_points_slice"] == b["n_points_slice"]
+    elif mode == "scans_gpu":
+        from oracle import ref_np as R
+        from pointcloud_amd import Config, CylinderAnalyzer
+        az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500))
+        loaded = []
+
+        def scan(k):
+            def load():
+                loaded.append(k)
+                return R.make_cylinder(40_000, 8, seed=200 + k, outlier_frac=0.01)
+            return load
+        res = sharding.analyze_scans_sharded(az, [scan(k) for k in range(5)])
+        ok &= loaded == sharding.scans_of_rank(5, rank, world)          # a rank loads only its own scans
+        ok &= len(res) == 5 and all(r is not None and len(r) == 8 for r in res)
+        if rank == 0:
+            for k in (0, 3, 4):
+                single = az.analyze_with_progress(R.make_cylinder(40_000, 8, seed=200 + k, outlier_frac=0.01))
+                ok &= res[k] == single
     flag = torch.tensor([1 if ok else 0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:

@@ -51,3 +51,16 @@ def test_sharded_analyzer_two_ranks_one_gpu():
     # two ranks share the one GPU for compute and exchange results over gloo
     r = run_workers(2, "analyze_gpu")
     assert r["ok"]
+
+
+def test_scans_go_round_robin():
+    assert sharding.scans_of_rank(64, 3, 8) == list(range(3, 64, 8))
+    assert sharding.scans_of_rank(2, 5, 8) == [] and sharding.scans_of_rank(0, 0, 1) == []
+    assert sorted(k for r in range(3) for k in sharding.scans_of_rank(10, r, 3)) == list(range(10))
+
+
+@pytest.mark.gpu
+def test_batch_of_scans_two_ranks_one_gpu():
+    # five scans over two ranks (3 + 2), uploads overlapped with the analyses, results exchanged over gloo
+    r = run_workers(2, "scans_gpu")
+    assert r["ok"]
