@@ -340,6 +340,12 @@ int pcfit_scan_free(pcfit_scan *scan);
 int pcfit_scan_bin_slices(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
                           int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
                           int64_t *total);
+/* Members of every window of the resident scan without materialising them:
+ * counts[s] = number of points with z_lo[s] <= z <= z_hi[s] (the n0 of
+ * analyzer.py:49-54 for all windows at once; what balancing the windows over
+ * several GPUs needs).  The count pass of the binning alone. */
+int pcfit_scan_window_counts(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
+                             int64_t *counts);
 int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
                                double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
                                double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets,

@@ -90,6 +90,7 @@ SIGNATURES = {
     "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
     "pcfit_scan_free": (C.c_int, [_vp]),
     "pcfit_scan_bin_slices": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "pcfit_scan_window_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
                                    + [_vp] * 13 + [_i64, _i64]),
     "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
@@ -355,6 +356,17 @@ class DeviceScan:
 
     def __len__(self):
         return self.n_points
+
+    def window_counts(self, z_lo, z_hi):
+        """Points per closed window [z_lo[s], z_hi[s]] (pcfit_scan_window_counts)."""
+        if not self._handle:
+            raise PcfitError("the DeviceScan was closed")
+        z_lo = _arr(z_lo, np.float64)
+        z_hi = _arr(z_hi, np.float64)
+        counts = np.zeros(z_lo.size, np.int64)
+        if z_lo.size:
+            check(lib().pcfit_scan_window_counts(self._handle, _p(z_lo), _p(z_hi), z_lo.size, _p(counts)))
+        return counts
 
 
 def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,

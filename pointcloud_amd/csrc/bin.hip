@@ -794,3 +794,32 @@ PCFIT_API int pcfit_scan_bin_slices(const pcfit_scan *scan, const double *z_lo, 
     return bin_resident(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, offsets, x_out, y_out, perm,
                         capacity, total);
 }
+
+// members per window of the resident scan: the count pass alone
+PCFIT_API int pcfit_scan_window_counts(const pcfit_scan *scan, const double *z_lo, const double *z_hi,
+                                       int64_t n_slices, int64_t *counts)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(scan, "window_counts: scan is null");
+    PCFIT_REQUIRE(n_slices >= 1 && z_lo && z_hi && counts, "window_counts: need n_slices >= 1 and non-null arrays");
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    PCFIT_REQUIRE(dev == scan->device, "window_counts: the scan lives on device %d, the current device is %d",
+                  scan->device, dev);
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
+    hipStream_t st = nullptr;
+    DevBuf dlo, dhi, doff, dws;
+    PCFIT_TRY(dlo.upload(z_lo, (size_t)n_slices * 8, st));
+    PCFIT_TRY(dhi.upload(z_hi, (size_t)n_slices * 8, st));
+    PCFIT_TRY(doff.alloc((size_t)(n_slices + 1) * 8));
+    PCFIT_TRY(dws.alloc(pcfit_bin_workspace_bytes(scan->n_points, n_slices)));
+    PCFIT_TRY(pcfit_bin_count_dev(scan->xyz.as<double>(), scan->n_points, dlo.as<double>(), dhi.as<double>(), n_slices,
+                                  geom, doff.as<int64_t>(), dws.p, dws.bytes, st));
+    std::vector<int64_t> off((size_t)n_slices + 1);
+    PCFIT_TRY(doff.download(off.data(), off.size() * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    for (int64_t s = 0; s < n_slices; s++)
+        counts[s] = off[(size_t)s + 1] - off[(size_t)s];
+    return PCFIT_OK;
+}

@@ -70,32 +70,62 @@ def analyze_sharded(analyzer, points, group=None, progress_callback=None):
     """CylinderAnalyzer.analyze_with_progress with the windows sharded over the
     ranks of ``group``: every rank bins and fits its own range of windows on its
     GPU, then the per-slice result dicts are exchanged so that every rank returns
-    the full, z-ordered list.  ``points`` is the whole scan on every rank (a rank
-    only ever touches the points of its own windows on the device)."""
+    the full, z-ordered list.  ``points`` is the whole scan on every rank, as an
+    (N, 3) array or a DeviceScan already on the rank's GPU."""
     import torch.distributed as dist
 
-    points = np.ascontiguousarray(points, dtype=np.float64)
-    if points.ndim != 2 or points.shape[1] != 3:
-        raise ValueError("Points must be Nx3 array")
-    if analyzer.z_min is not None and analyzer.z_max is not None:
+    from ._ffi import DeviceScan
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    dz = analyzer.config.z_step / 2.0
+    ranged = analyzer.z_min is not None and analyzer.z_max is not None
+    if isinstance(points, DeviceScan) or not ranged:
+        # The scan goes to this rank's GPU once, whole: the z range, the window populations (the count pass of
+        # the binning) and the analysis of the rank's own windows all read that copy, and points of other ranks'
+        # windows are simply never binned. No pass over the points on the host.
+        own = not isinstance(points, DeviceScan)
+        if own:
+            points = np.ascontiguousarray(points, dtype=np.float64)
+            if points.ndim != 2 or points.shape[1] != 3:
+                raise ValueError("Points must be Nx3 array")
+        elif ranged:
+            raise ValueError("a DeviceScan cannot be combined with Config.z_min / z_max: pass the array")
+        scan = DeviceScan(points) if own and len(points) else points
+        try:
+            z_centers = analyzer.calculate_z_centers(scan)
+            counts = (scan.window_counts(z_centers - dz, z_centers + dz) if len(z_centers) and len(scan)
+                      else np.zeros(len(z_centers), np.int64))
+            bounds = split_by_points(counts, world)
+            s0, s1 = shard_range(bounds, rank)
+            mine = []
+            if s1 > s0:
+                for res, _, warn in analyzer._analyze_windows(scan, z_centers[s0:s1]):
+                    if warn is None:
+                        mine.append(res)
+        finally:
+            if own and isinstance(scan, DeviceScan):
+                scan.close()
+    else:
+        # a configured z range filters the points first (analyzer.py:190-196), which needs the array
+        points = np.ascontiguousarray(points, dtype=np.float64)
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("Points must be Nx3 array")
         points = points[(points[:, 2] >= analyzer.z_min) & (points[:, 2] <= analyzer.z_max)]
         if len(points) == 0:
             raise ValueError(f"No points in specified Z range [{analyzer.z_min}, {analyzer.z_max}]")
-    z_centers = analyzer.calculate_z_centers(points)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    # balance by the window populations (one cheap histogram of z on the host)
-    dz = analyzer.config.z_step / 2.0
-    edges = np.concatenate([z_centers - dz, z_centers[-1:] + dz]) if len(z_centers) else np.zeros(1)
-    counts = np.histogram(points[:, 2], bins=edges)[0] if len(z_centers) else np.zeros(0, np.int64)
-    bounds = split_by_points(counts, world)
-    s0, s1 = shard_range(bounds, rank)
-    mine = []
-    if s1 > s0:
-        lo, hi = z_centers[s0] - dz, z_centers[s1 - 1] + dz
-        sel = points[(points[:, 2] >= lo) & (points[:, 2] <= hi)]
-        for res, _, warn in analyzer._analyze_windows(np.ascontiguousarray(sel), z_centers[s0:s1]):
-            if warn is None:
-                mine.append(res)
+        z_centers = analyzer.calculate_z_centers(points)
+        # balance by the window populations (one histogram of z on the host)
+        edges = np.concatenate([z_centers - dz, z_centers[-1:] + dz]) if len(z_centers) else np.zeros(1)
+        counts = np.histogram(points[:, 2], bins=edges)[0] if len(z_centers) else np.zeros(0, np.int64)
+        bounds = split_by_points(counts, world)
+        s0, s1 = shard_range(bounds, rank)
+        mine = []
+        if s1 > s0:
+            lo, hi = z_centers[s0] - dz, z_centers[s1 - 1] + dz
+            sel = points[(points[:, 2] >= lo) & (points[:, 2] <= hi)]
+            for res, _, warn in analyzer._analyze_windows(np.ascontiguousarray(sel), z_centers[s0:s1]):
+                if warn is None:
+                    mine.append(res)
     everyone = [None] * world
     dist.all_gather_object(everyone, mine, group=group)
     results = [r for part in everyone for r in part]

@@ -754,6 +754,12 @@ def test_resident_scan_gives_the_same_analysis():
         (res_b, cand_b, slc_b, fit_b, ov_b), edge_b, _ = az.process_slice(scan, zc)
         assert res_a == res_b and fit_a == fit_b and np.array_equal(slc_a, slc_b) and edge_a.equals(edge_b)
         assert np.array_equal(ov_a["dev_uniform"], ov_b["dev_uniform"], equal_nan=True)
+        # window populations from the count pass alone (closed windows: a point on a shared edge counts twice)
+        zcs = az.calculate_z_centers(pts)
+        z = pts[:, 2]
+        assert np.array_equal(scan.window_counts(zcs - 1.0, zcs + 1.0),
+                              [np.count_nonzero((z >= c - 1.0) & (z <= c + 1.0)) for c in zcs])
+        assert scan.window_counts([], []).size == 0
     assert seen[-1] == 100 and seen == sorted(seen)
     assert len(got) == len(want) == len(again) > 20
     for a, b, c in zip(want, got, again):
