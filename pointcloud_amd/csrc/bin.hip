@@ -42,6 +42,17 @@ struct BinGeom {
     int64_t S;
 };
 
+// Workgroups are handed to the 8 XCDs in turn (workgroup b runs on XCD b % 8) and every XCD has its own L2.
+// Consecutive chunks write neighbouring parts of every window's output, often parts of the same cache line; with
+// this mapping an XCD works through one contiguous range of chunks, so those parts meet in one L2.
+constexpr int N_XCD = 8;
+__device__ __forceinline__ int64_t chunk_of_block(int64_t b, int64_t chunks)
+{
+    const int64_t xcd = b % N_XCD, idx = b / N_XCD;
+    const int64_t q = chunks / N_XCD, r = chunks % N_XCD;
+    return xcd * q + (xcd < r ? xcd : r) + idx;
+}
+
 // windows containing z: k1 (or -1) and, if a second one, k1 + 1 (has2)
 __device__ __forceinline__ void windows_of(double z, const BinGeom &g, const double *__restrict__ z_lo,
                                            const double *__restrict__ z_hi, int32_t &k1, bool &has2)
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
 {
     // cursor[s]: where this wave's next member of window s goes, relative to the window's first slot
     extern __shared__ uint32_t cursor[];
-    const int64_t c = blockIdx.x;
+    const int64_t c = chunk_of_block(blockIdx.x, gridDim.x);
     const int lane = threadIdx.x;
     const uint64_t below = (1ull << lane) - 1ull;
     for (int64_t s = lane; s < g.S; s += 64)
@@ -375,7 +386,7 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
     uint32_t *sidx = wave_sum + WAVES;                                   // CAP, with PERM
     uint8_t *skey = reinterpret_cast<uint8_t *>(sidx + (PERM ? CAP : 0));        // CAP
 
-    const int64_t c = blockIdx.x;
+    const int64_t c = chunk_of_block(blockIdx.x, gridDim.x);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t *cw = cnt + w * S;

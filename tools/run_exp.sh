@@ -1,5 +1,5 @@
 #!/bin/bash
-timeout -k 10 300 python3 bench.py --no-cpu-baseline | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['ms_per_step']); [print(k) for k in d['kernels']]" || exit 1
+mkdir -p gpurun_out
+timeout -k 10 600 python3 -u tests/fuzz_parity.py 200 31000 > gpurun_out/fuzz_bin.txt 2>&1 || { tail -20 gpurun_out/fuzz_bin.txt; exit 1; }
+tail -1 gpurun_out/fuzz_bin.txt
+timeout -k 10 300 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread -k "bin or scan" 2>&1 | tail -2
