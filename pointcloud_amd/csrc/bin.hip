@@ -36,11 +36,23 @@ constexpr int BIN_SEG = 64;            // chunk rows per scan segment
 constexpr int BIN_UNROLL = 4;          // 64-point trips whose loads are issued together
 constexpr int64_t BIN_MAX_SLICES = 16384;
 constexpr double BIN_EDGE_EPS = 1e-6;  // in units of the window step
+// Points from which more than BIN_STG_MAX_SLICES windows are binned in two levels. Measured on resident scans in
+// random z order: 100 M points / 2000 windows 10.7 -> 9.3 ms per analysis, 50 M / 400 windows 3.53 -> 3.36 ms,
+// 10 M / 400 windows 1.60 -> 1.70 ms (the second count pass and the extra launches cost more than they save).
+constexpr int64_t BIN_TWO_LEVEL_MIN = 32'000'000;
 
 struct BinGeom {
     double lo0, inv_step, rel_width;   // rel_width = (z_hi[0]-z_lo[0]) / step
     int64_t S;
 };
+
+// where the points are read from: coordinate i of point k at x[k * stride] etc. (a scan of xyz rows: x = xyz,
+// y = xyz + 1, z = xyz + 2, stride 3; three separate arrays: stride 1)
+struct BinSrc {
+    const double *x, *y, *z;
+    int64_t stride;
+};
+static BinSrc rows_of(const double *xyz) { return BinSrc{xyz, xyz + 1, xyz + 2, 3}; }
 
 // Workgroups are handed to the 8 XCDs in turn (workgroup b runs on XCD b % 8) and every XCD has its own L2.
 // Consecutive chunks write neighbouring parts of every window's output, often parts of the same cache line; with
@@ -89,7 +101,7 @@ __device__ __forceinline__ void windows_of(double z, const BinGeom &g, const dou
     }
 }
 
-__global__ __launch_bounds__(64) void bin_count_kernel(const double *__restrict__ xyz, int64_t n, int64_t chunk_len,
+__global__ __launch_bounds__(64) void bin_count_kernel(BinSrc src, int64_t n, int64_t chunk_len,
                                                       const double *__restrict__ z_lo,
                                                       const double *__restrict__ z_hi, BinGeom g,
                                                       uint32_t *__restrict__ counts)
@@ -106,7 +118,7 @@ __global__ __launch_bounds__(64) void bin_count_kernel(const double *__restrict_
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
             const int64_t i = base + 64 * u;
-            z[u] = i < end ? xyz[3 * i + 2] : __longlong_as_double(0x7ff8000000000000ll);   // NaN: no window
+            z[u] = i < end ? src.z[i * src.stride] : __longlong_as_double(0x7ff8000000000000ll);   // NaN: no window
         }
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
@@ -235,7 +247,7 @@ __device__ __forceinline__ void key_ballots(uint32_t key, uint64_t (&bit_ballot)
 
 // The x, y, z of BIN_UNROLL trips of 64 points, all loads issued before any is used.  Lanes past the end
 // read the chunk's last point (a load without a branch) and get NaN for z: no window.
-__device__ __forceinline__ void load_trips(const double *__restrict__ xyz, int64_t sbase, int64_t end, int lane,
+__device__ __forceinline__ void load_trips(const BinSrc &src, int64_t sbase, int64_t end, int lane,
                                            double (&lx)[BIN_UNROLL], double (&ly)[BIN_UNROLL],
                                            double (&lz)[BIN_UNROLL])
 {
@@ -243,15 +255,15 @@ __device__ __forceinline__ void load_trips(const double *__restrict__ xyz, int64
     for (int u = 0; u < BIN_UNROLL; u++) {
         const int64_t i = sbase + 64 * u + lane;
         const int64_t ic = i < end ? i : end - 1;
-        lx[u] = xyz[3 * ic];
-        ly[u] = xyz[3 * ic + 1];
-        const double z = xyz[3 * ic + 2];
+        lx[u] = src.x[ic * src.stride];
+        ly[u] = src.y[ic * src.stride];
+        const double z = src.z[ic * src.stride];
         lz[u] = i < end ? z : __longlong_as_double(0x7ff8000000000000ll);
     }
 }
 
 template <int NBITS, bool PERM>
-__global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restrict__ xyz, int64_t n, int64_t chunk_len,
+__global__ __launch_bounds__(64) void bin_scatter_kernel(BinSrc src, int64_t n, int64_t chunk_len,
                                                         const double *__restrict__ z_lo,
                                                         const double *__restrict__ z_hi, BinGeom g,
                                                         const uint32_t *__restrict__ counts,
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(64) void bin_scatter_kernel(const double *__restric
     for (int64_t sbase = begin; sbase < end; sbase += 64 * BIN_UNROLL) {
         // the loads of BIN_UNROLL trips are issued together; the trips are then placed in order
         double lx[BIN_UNROLL], ly[BIN_UNROLL], lz[BIN_UNROLL];
-        load_trips(xyz, sbase, end, lane, lx, ly, lz);
+        load_trips(src, sbase, end, lane, lx, ly, lz);
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
             if (sbase + 64 * u >= end)
@@ -368,10 +380,11 @@ template <int TILE, int WAVES, bool PERM> static size_t bin_stage_lds(int64_t S)
 
 template <int NBITS, bool PERM, int TILE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
-    const double *__restrict__ xyz, int64_t n, int64_t chunk_len, const double *__restrict__ z_lo,
+    BinSrc src, int64_t n, int64_t chunk_len, const double *__restrict__ z_lo,
     const double *__restrict__ z_hi, BinGeom g, const uint32_t *__restrict__ counts,
     const int64_t *__restrict__ segbase, const int64_t *__restrict__ offsets, double *__restrict__ x_out,
-    double *__restrict__ y_out, int64_t *__restrict__ perm)
+    double *__restrict__ y_out, int64_t *__restrict__ perm, double *__restrict__ z_out,
+    const int64_t *__restrict__ idx_in)
 {
     constexpr int TRIPS = TILE / (64 * WAVES);
     constexpr int CAP = bin_stage_cap<TILE>();
@@ -409,9 +422,9 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
             for (int u = 0; u < TRIPS; u++) {
                 const int64_t i = wbase + 64 * u + lane;
                 const int64_t ic = i < end ? i : end - 1;
-                px[u] = xyz[3 * ic];
-                py[u] = xyz[3 * ic + 1];
-                pz[u] = xyz[3 * ic + 2];
+                px[u] = src.x[ic * src.stride];
+                py[u] = src.y[ic * src.stride];
+                pz[u] = src.z[ic * src.stride];
             }
 #pragma unroll
             for (int u = 0; u < TRIPS; u++) {
@@ -533,14 +546,17 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 }
             } else {
                 const int64_t d1 = gdelta[k1] + (int64_t)p1;
+                const int64_t from = tbase + local;
                 x_out[d1] = px[u];
                 y_out[d1] = py[u];
-                if (PERM) perm[d1] = tbase + local;
+                if (PERM && perm) perm[d1] = idx_in ? idx_in[from] : from;
+                if (PERM && z_out) z_out[d1] = src.z[from * src.stride];
                 if (has2) {
                     const int64_t d2 = gdelta[k1 + 1] + (int64_t)p2;
                     x_out[d2] = px[u];
                     y_out[d2] = py[u];
-                    if (PERM) perm[d2] = tbase + local;
+                    if (PERM && perm) perm[d2] = idx_in ? idx_in[from] : from;
+                    if (PERM && z_out) z_out[d2] = src.z[from * src.stride];
                 }
             }
         }
@@ -552,7 +568,13 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 const int64_t d = gdelta[skey[e]] + (int64_t)e;
                 x_out[d] = v.x;
                 y_out[d] = v.y;
-                if (PERM) perm[d] = tbase + sidx[e];
+                if (PERM) {
+                    // (with PERM the source index of every staged point is kept: it serves perm, and z of the
+                    // point when the caller wants z scattered as well - a re-read of what this tile just loaded)
+                    const int64_t from = tbase + sidx[e];
+                    if (perm) perm[d] = idx_in ? idx_in[from] : from;
+                    if (z_out) z_out[d] = src.z[from * src.stride];
+                }
             }
         }
         // (the next tile's first barrier comes before anything read in pass 3 is written again)
@@ -637,23 +659,24 @@ PCFIT_API size_t pcfit_bin_workspace_bytes(int64_t n_points, int64_t n_slices)
     return bin_plan(std::max<int64_t>(n_points, 0), n_slices).bytes;
 }
 
-PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
-                                  int64_t n_slices, const double *window_geom, int64_t *offsets, void *workspace,
-                                  size_t workspace_bytes, void *stream)
+namespace pcfit {
+
+// the count pass and its scans: offsets (device, S + 1) and the workspace the scatter pass reads
+static int count_launch(const BinSrc &src, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
+                        const double *window_geom, int64_t *offsets, void *workspace, size_t workspace_bytes,
+                        hipStream_t st)
 {
-    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     if (n_slices > BIN_MAX_SLICES) {
         set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)n_slices);
         return PCFIT_ERR_UNSUPPORTED;
     }
-    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && (xyz || n_points == 0), "bin: null pointer");
+    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && (src.x || n_points == 0), "bin: null pointer");
     const BinPlan p = bin_plan(n_points, n_slices);
     if (!workspace || workspace_bytes < p.bytes) {
         set_error("bin: workspace of %zu bytes needed", p.bytes);
         return PCFIT_ERR_WORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
     BinGeom g;
     int rc = bin_geom(window_geom, n_slices, g);
     if (rc) return rc;
@@ -662,7 +685,7 @@ PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const dou
     int64_t *segsum = reinterpret_cast<int64_t *>(ws + p.segsum_off);
     int64_t *totals = reinterpret_cast<int64_t *>(ws + p.totals_off);
     const int64_t S = n_slices;
-    bin_count_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(xyz, n_points, p.chunk_len, z_lo, z_hi,
+    bin_count_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(src, n_points, p.chunk_len, z_lo, z_hi,
                                                                               g, counts);
     PCFIT_LAUNCH_CHECK();
     const dim3 cols((unsigned)((S + 255) / 256), (unsigned)p.segs);
@@ -677,21 +700,21 @@ PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const dou
     return PCFIT_OK;
 }
 
-PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
-                                    int64_t n_slices, const double *window_geom, const int64_t *offsets,
-                                    double *x_out, double *y_out, int64_t *perm, void *workspace,
-                                    size_t workspace_bytes, void *stream)
+// the scatter pass.  z_out (z scattered like x and y) and idx_in (perm receives idx_in[k] instead of k) are
+// for the staged kernel only, i.e. for at most BIN_STG_MAX_SLICES windows.
+static int scatter_launch(const BinSrc &src, int64_t n_points, const double *z_lo, const double *z_hi,
+                          int64_t n_slices, const double *window_geom, const int64_t *offsets, double *x_out,
+                          double *y_out, int64_t *perm, double *z_out, const int64_t *idx_in, void *workspace,
+                          size_t workspace_bytes, hipStream_t st)
 {
-    PCFIT_ENTER();
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1 && n_slices <= BIN_MAX_SLICES, "bin: bad sizes");
-    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && x_out && y_out && (xyz || n_points == 0),
+    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && x_out && y_out && (src.x || n_points == 0),
                   "bin: null pointer");
     const BinPlan p = bin_plan(n_points, n_slices);
     if (!workspace || workspace_bytes < p.bytes) {
         set_error("bin: workspace of %zu bytes needed (the one pcfit_bin_count_dev filled)", p.bytes);
         return PCFIT_ERR_WORKSPACE;
     }
-    hipStream_t st = as_stream(stream);
     BinGeom g;
     int rc = bin_geom(window_geom, n_slices, g);
     if (rc) return rc;
@@ -702,7 +725,10 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     while ((1ll << nbits) < n_slices + 2)
         nbits++;
     static const int staged = [] { const char *e = getenv("PCFIT_BIN_STAGED"); return e ? atoi(e) : 1; }();
-    if (staged && n_slices <= BIN_STG_MAX_SLICES) {
+    const bool extras = z_out != nullptr || idx_in != nullptr;
+    PCFIT_REQUIRE(!extras || n_slices <= BIN_STG_MAX_SLICES, "bin: z_out / idx_in need at most %d windows",
+                  BIN_STG_MAX_SLICES);
+    if ((staged || extras) && n_slices <= BIN_STG_MAX_SLICES) {
         int rc2 = PCFIT_OK;
         with_key_bits(nbits, [&](auto tag) {
             constexpr int NB = decltype(tag)::value < 10 ? decltype(tag)::value : 10;    // 258 keys at most
@@ -715,13 +741,14 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
                     rc2 = PCFIT_ERR_HIP;
                     return;
                 }
-                kern<<<dim3((unsigned)p.chunks), dim3(64 * waves), lds, st>>>(
-                    xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+                kern<<<dim3((unsigned)p.chunks), dim3(64 * waves), lds, st>>>(src, n_points, p.chunk_len, z_lo, z_hi, g,
+                                                                              counts, segsum, offsets, x_out, y_out,
+                                                                              perm, z_out, idx_in);
             };
             // Tiles of 2048 points on four waves. Measured against 4096 x 4 and 4096 x 8: longer tiles make
             // longer runs (50 M points in random order, 57 windows, no perm: 0.47 vs 0.56 ms) but leave one or two
             // workgroups per CU, which loses more wherever the input is partly ordered, small, or perm is wanted.
-            if (perm)
+            if (perm || z_out)
                 launch(&bin_scatter_staged_kernel<NB, true, 2048, 4>, bin_stage_lds<2048, 4, true>(n_slices), 4);
             else
                 launch(&bin_scatter_staged_kernel<NB, false, 2048, 4>, bin_stage_lds<2048, 4, false>(n_slices), 4);
@@ -734,46 +761,200 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
         constexpr int NB = decltype(tag)::value;
         if (perm)
             bin_scatter_kernel<NB, true><<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
-                xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+                src, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
         else
             bin_scatter_kernel<NB, false><<<dim3((unsigned)p.chunks), dim3(64), (size_t)n_slices * 4, st>>>(
-                xyz, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
+                src, n_points, p.chunk_len, z_lo, z_hi, g, counts, segsum, offsets, x_out, y_out, perm);
     });
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
 
-// count, offsets to the host, scatter, slices to the host: the scan is on the device already
+// Two levels for many windows.  With more than BIN_STG_MAX_SLICES windows the scatter cannot order its tiles in
+// LDS, and storing every point on its own costs several times the output in HBM writes when the points come in no
+// z order.  Level 1 scatters x, y, z (and the source index when perm is wanted) into groups of BIN_STG_MAX_SLICES
+// consecutive windows, each group one closed window from the first window's lower to the last one's upper edge;
+// level 2 bins every group into its own windows.  Both levels run the staged kernel.  A point on the edge shared
+// by two groups goes into both and each group keeps it for its own window only, so the result - members, order,
+// bytes - is that of the single pass.
+static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
+                         bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
+                         DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st)
+{
+    const int64_t W = BIN_STG_MAX_SLICES, G = (S + W - 1) / W;
+    // level 1: the groups as windows (the last one padded to the common width; what it takes in beyond the last
+    // real window finds no window at level 2)
+    std::vector<double> glo((size_t)G), ghi((size_t)G);
+    for (int64_t g = 0; g < G; g++) {
+        glo[(size_t)g] = z_lo[g * W];
+        ghi[(size_t)g] = (g + 1) * W <= S ? z_hi[(g + 1) * W - 1] : glo[(size_t)g] + (ghi[0] - glo[0]);
+    }
+    double geom1[3];
+    PCFIT_TRY(bin_check_windows(glo.data(), ghi.data(), G, geom1));
+    DevBuf dglo, dghi, dgoff, dws1, x1, y1, z1, i1;
+    PCFIT_TRY(dglo.upload(glo.data(), (size_t)G * 8, st));
+    PCFIT_TRY(dghi.upload(ghi.data(), (size_t)G * 8, st));
+    PCFIT_TRY(dgoff.alloc((size_t)(G + 1) * 8));
+    PCFIT_TRY(dws1.alloc(bin_plan(n_points, G).bytes));
+    const BinSrc rows = rows_of(dxyz);
+    PCFIT_TRY(count_launch(rows, n_points, dglo.as<double>(), dghi.as<double>(), G, geom1, dgoff.as<int64_t>(), dws1.p,
+                           dws1.bytes, st));
+    std::vector<int64_t> goff((size_t)G + 1);
+    PCFIT_TRY(dgoff.download(goff.data(), goff.size() * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    const int64_t n1 = goff[(size_t)G];
+    PCFIT_TRY(x1.alloc((size_t)n1 * 8));
+    PCFIT_TRY(y1.alloc((size_t)n1 * 8));
+    PCFIT_TRY(z1.alloc((size_t)n1 * 8));
+    if (want_perm) PCFIT_TRY(i1.alloc((size_t)n1 * 8));
+    if (n1 > 0)
+        PCFIT_TRY(scatter_launch(rows, n_points, dglo.as<double>(), dghi.as<double>(), G, geom1, dgoff.as<int64_t>(),
+                                 x1.as<double>(), y1.as<double>(), want_perm ? i1.as<int64_t>() : nullptr,
+                                 z1.as<double>(), nullptr, dws1.p, dws1.bytes, st));
+    // level 2, counts: every group against its own windows (one workspace and one offsets array, a part each)
+    std::vector<size_t> ws_at((size_t)G + 1, 0);
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t Sg = std::min<int64_t>(W, S - g * W), ng = goff[(size_t)g + 1] - goff[(size_t)g];
+        ws_at[(size_t)g + 1] = ws_at[(size_t)g] + (ng > 0 ? bin_plan(ng, Sg).bytes : 0);
+    }
+    DevBuf ws2, off2;
+    PCFIT_TRY(ws2.alloc(std::max<size_t>(ws_at[(size_t)G], 8)));
+    PCFIT_TRY(off2.alloc((size_t)(S + G) * 8));                      // group g's Sg + 1 offsets start at g * W + g
+    PCFIT_HIP(hipMemsetAsync(off2.p, 0, (size_t)(S + G) * 8, st));   // (groups without points are not counted)
+    std::vector<double> geom2((size_t)G * 3);
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0), ng = goff[(size_t)g + 1] - goff[(size_t)g];
+        double *gm = &geom2[(size_t)g * 3];
+        gm[0] = z_lo[s0];
+        gm[1] = z_hi[s0];
+        gm[2] = z_lo[s0 + Sg - 1];
+        if (ng == 0)
+            continue;
+        const BinSrc cols{x1.as<double>() + goff[(size_t)g], y1.as<double>() + goff[(size_t)g],
+                          z1.as<double>() + goff[(size_t)g], 1};
+        PCFIT_TRY(count_launch(cols, ng, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, gm,
+                               off2.as<int64_t>() + s0 + g, static_cast<char *>(ws2.p) + ws_at[(size_t)g],
+                               ws_at[(size_t)g + 1] - ws_at[(size_t)g], st));
+    }
+    std::vector<int64_t> hoff((size_t)(S + G));
+    PCFIT_TRY(off2.download(hoff.data(), hoff.size() * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> base((size_t)G + 1, 0);
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0);
+        const int64_t *og = &hoff[(size_t)(s0 + g)];
+        for (int64_t j = 0; j < Sg; j++)
+            offsets[s0 + j] = base[(size_t)g] + og[j];
+        base[(size_t)g + 1] = base[(size_t)g] + og[Sg];
+    }
+    const int64_t total = base[(size_t)G];
+    offsets[S] = total;
+    if (capacity >= 0 && total > capacity)
+        return PCFIT_OK;                       // (the caller reports it; nothing is scattered)
+    PCFIT_TRY(doff.upload(offsets, (size_t)(S + 1) * 8, st));
+    PCFIT_TRY(dx.alloc((size_t)total * 8));
+    PCFIT_TRY(dy.alloc((size_t)total * 8));
+    if (want_perm) PCFIT_TRY(dperm.alloc((size_t)total * 8));
+    // level 2, scatter: group g writes at base[g] with its own offsets
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0), ng = goff[(size_t)g + 1] - goff[(size_t)g];
+        if (ng == 0 || base[(size_t)g + 1] == base[(size_t)g])
+            continue;
+        const BinSrc cols{x1.as<double>() + goff[(size_t)g], y1.as<double>() + goff[(size_t)g],
+                          z1.as<double>() + goff[(size_t)g], 1};
+        PCFIT_TRY(scatter_launch(cols, ng, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, &geom2[(size_t)g * 3],
+                                 off2.as<int64_t>() + s0 + g, dx.as<double>() + base[(size_t)g],
+                                 dy.as<double>() + base[(size_t)g],
+                                 want_perm ? dperm.as<int64_t>() + base[(size_t)g] : nullptr, nullptr,
+                                 want_perm ? i1.as<int64_t>() + goff[(size_t)g] : nullptr,
+                                 static_cast<char *>(ws2.p) + ws_at[(size_t)g],
+                                 ws_at[(size_t)g + 1] - ws_at[(size_t)g], st));
+    }
+    // (the level-1 arrays are released when this returns: the stream runs the scatters first, as every other
+    // block handed back to the cache relies on)
+    return PCFIT_OK;
+}
+
+// Bin the scan on the device: offsets to the host (and to doff), x, y (and perm) left in dx, dy (dperm).
+// With capacity >= 0 and more members than that, only the offsets are produced.
+int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
+                  bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
+                  DevBuf &dperm, hipStream_t st)
+{
+    PCFIT_REQUIRE(n_points >= 0 && S >= 1, "bin: need n_points >= 0 and n_slices >= 1");
+    PCFIT_REQUIRE(z_lo && z_hi && offsets, "bin: null pointer");
+    if (S > BIN_MAX_SLICES) {
+        set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)S);
+        return PCFIT_ERR_UNSUPPORTED;
+    }
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
+    DevBuf dlo, dhi, dws;
+    PCFIT_TRY(dlo.upload(z_lo, (size_t)S * 8, st));
+    PCFIT_TRY(dhi.upload(z_hi, (size_t)S * 8, st));
+    PCFIT_TRY(doff.alloc((size_t)(S + 1) * 8));
+    // (read at every call so that a test can switch between the two forms; negative = never)
+    const char *env = getenv("PCFIT_BIN_TWO_LEVEL_MIN");
+    const int64_t two_level_min = env ? atoll(env) : BIN_TWO_LEVEL_MIN;
+    if (S > BIN_STG_MAX_SLICES && two_level_min >= 0 && n_points >= two_level_min)
+        return bin_two_level(dxyz, n_points, z_lo, z_hi, S, want_perm, capacity, offsets, doff, dx, dy, dperm, dlo,
+                             dhi, st);
+    const BinSrc rows = rows_of(dxyz);
+    PCFIT_TRY(dws.alloc(bin_plan(n_points, S).bytes));
+    PCFIT_TRY(count_launch(rows, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(), dws.p,
+                           dws.bytes, st));
+    PCFIT_TRY(doff.download(offsets, (size_t)(S + 1) * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    const int64_t total = offsets[S];
+    if (capacity >= 0 && total > capacity)
+        return PCFIT_OK;
+    PCFIT_TRY(dx.alloc((size_t)total * 8));
+    PCFIT_TRY(dy.alloc((size_t)total * 8));
+    if (want_perm) PCFIT_TRY(dperm.alloc((size_t)total * 8));
+    if (total > 0)
+        PCFIT_TRY(scatter_launch(rows, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(),
+                                 dx.as<double>(), dy.as<double>(), want_perm ? dperm.as<int64_t>() : nullptr, nullptr,
+                                 nullptr, dws.p, dws.bytes, st));
+    return PCFIT_OK;
+}
+
+}  // namespace pcfit
+
+PCFIT_API int pcfit_bin_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                  int64_t n_slices, const double *window_geom, int64_t *offsets, void *workspace,
+                                  size_t workspace_bytes, void *stream)
+{
+    PCFIT_ENTER();
+    return count_launch(rows_of(xyz), n_points, z_lo, z_hi, n_slices, window_geom, offsets, workspace, workspace_bytes,
+                        as_stream(stream));
+}
+
+PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                    int64_t n_slices, const double *window_geom, const int64_t *offsets,
+                                    double *x_out, double *y_out, int64_t *perm, void *workspace,
+                                    size_t workspace_bytes, void *stream)
+{
+    PCFIT_ENTER();
+    return scatter_launch(rows_of(xyz), n_points, z_lo, z_hi, n_slices, window_geom, offsets, x_out, y_out, perm,
+                          nullptr, nullptr, workspace, workspace_bytes, as_stream(stream));
+}
+
+// bin on the device, slices to the host: the scan is on the device already
 static int bin_resident(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
                         int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
                         int64_t *total)
 {
-    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
-    PCFIT_REQUIRE(z_lo && z_hi && offsets && total, "bin: null pointer");
-    double geom[3];
-    PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
+    PCFIT_REQUIRE(total, "bin: null pointer");
     hipStream_t st = nullptr;
-    DevBuf dlo, dhi, doff, dws, dx, dy, dperm;
-    const size_t ws_bytes = pcfit_bin_workspace_bytes(n_points, n_slices);
-    PCFIT_TRY(dlo.upload(z_lo, (size_t)n_slices * 8, st));
-    PCFIT_TRY(dhi.upload(z_hi, (size_t)n_slices * 8, st));
-    PCFIT_TRY(doff.alloc((size_t)(n_slices + 1) * 8));
-    PCFIT_TRY(dws.alloc(ws_bytes));
-    PCFIT_TRY(pcfit_bin_count_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
-                                  doff.as<int64_t>(), dws.p, dws.bytes, st));
-    PCFIT_TRY(doff.download(offsets, (size_t)(n_slices + 1) * 8, st));
-    PCFIT_HIP(hipStreamSynchronize(st));
+    DevBuf doff, dx, dy, dperm;
+    const int64_t room = (x_out == nullptr || y_out == nullptr) ? 0 : std::max<int64_t>(capacity, 0);
+    PCFIT_TRY(bin_on_device(dxyz, n_points, z_lo, z_hi, n_slices, perm != nullptr, room, offsets, doff, dx, dy, dperm,
+                            st));
     *total = offsets[n_slices];
-    if (*total > capacity || ((x_out == nullptr || y_out == nullptr) && *total > 0)) {
+    if (*total > room) {
         set_error("bin: outputs hold %lld points, %lld needed", (long long)capacity, (long long)*total);
         return PCFIT_ERR_INVALID;
     }
-    PCFIT_TRY(dx.alloc((size_t)*total * 8));
-    PCFIT_TRY(dy.alloc((size_t)*total * 8));
-    if (perm) PCFIT_TRY(dperm.alloc((size_t)*total * 8));
-    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), n_slices, geom,
-                                    doff.as<int64_t>(), dx.as<double>(), dy.as<double>(),
-                                    perm ? dperm.as<int64_t>() : nullptr, dws.p, dws.bytes, st));
     PCFIT_TRY(dx.download(x_out, (size_t)*total * 8, st));
     PCFIT_TRY(dy.download(y_out, (size_t)*total * 8, st));
     if (perm) PCFIT_TRY(dperm.download(perm, (size_t)*total * 8, st));

@@ -92,6 +92,13 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+// bin.hip: the scan (rows of xyz on the device) binned into the windows - offsets to the host and to doff,
+// x, y (and perm) left on the device; in two levels when the windows are many.  With capacity >= 0 and more
+// members than that only the offsets are produced.
+int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
+                  bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
+                  DevBuf &dperm, hipStream_t st);
+
 }  // namespace pcfit
 
 // A scan kept on the device between calls (the opaque pcfit_scan of the header).

@@ -747,24 +747,10 @@ static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo,
     PCFIT_REQUIRE(cand_capacity >= 0 && (cand_capacity == 0 || (cand_x && cand_y && mask && radius && theta)),
                   "scan_hybrid: null pointer");
     PCFIT_REQUIRE(max_trials >= 0, "scan_hybrid: max_trials negative");
-    double geom[3];
-    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
-    DevBuf dlo, dhi, doff, dbw, dx, dy;
-    PCFIT_TRY(dlo.upload(z_lo, S * 8, st));
-    PCFIT_TRY(dhi.upload(z_hi, S * 8, st));
-    PCFIT_TRY(doff.alloc((S + 1) * 8));
-    const size_t bws = pcfit_bin_workspace_bytes(n_points, S);
-    PCFIT_TRY(dbw.alloc(bws));
-    PCFIT_TRY(pcfit_bin_count_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(),
-                                  dbw.p, bws, st));
-    PCFIT_TRY(doff.download(offsets, (S + 1) * 8, st));
-    PCFIT_HIP(hipStreamSynchronize(st));
+    DevBuf doff, dx, dy, dperm;
+    PCFIT_TRY(bin_on_device(dxyz, n_points, z_lo, z_hi, S, false, -1, offsets, doff, dx, dy, dperm, st));
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
-    PCFIT_TRY(dx.alloc((size_t)total * 8));
-    PCFIT_TRY(dy.alloc((size_t)total * 8));
-    PCFIT_TRY(pcfit_bin_scatter_dev(dxyz, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(),
-                                    dx.as<double>(), dy.as<double>(), nullptr, dbw.p, bws, st));
     return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
                        max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, seed, status, fit,
                        nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,

@@ -190,7 +190,7 @@ def bin_round(seed):
     grid that hits the edges, NaN and out-of-range values."""
     g = np.random.default_rng(seed)
     n = int(g.choice([0, 1, 63, 64, 65, 4095, 4096, 4097, 100_000, 300_000]))
-    S = int(g.choice([1, 2, 3, 31, 32, 33, 57, 200, 255, 256, 257, 1000, 3000]))
+    S = int(g.choice([1, 2, 3, 31, 32, 33, 57, 200, 255, 256, 257, 511, 512, 513, 1000, 3000]))
     step = float(g.choice([2.0, 0.5, 0.1, 1.0 / 3.0]))
     width = step * float(g.choice([1.0, 1.0, 0.5, 0.999]))
     z0 = float(g.choice([0.0, -17.25, 1000.0]))
@@ -207,7 +207,10 @@ def bin_round(seed):
     if n > 10:
         z[g.integers(0, n, 3)] = np.nan
     pts = np.stack([g.normal(size=n), g.normal(size=n), z], 1) if n else np.zeros((0, 3))
+    # more than 256 windows: in one pass, or through groups of 256 windows
+    os.environ["PCFIT_BIN_TWO_LEVEL_MIN"] = str(g.choice([-1, 0]))
     off, x, y, perm = F.bin_slices(pts, lo, hi)
+    del os.environ["PCFIT_BIN_TWO_LEVEL_MIN"]
     o_ref, p_ref = N.bin_slices(pts, lo, hi)
     if not np.array_equal(off, o_ref):
         note(seed, -1, "bin offsets", f"[n={n} S={S} step={step} width={width} {mode}]")

@@ -8,6 +8,7 @@ indices, histograms, arg-max / arg-min; <= 1e-9 relative for Kasa and LM
 leaves undetermined beyond ~1e-8); angles within one rounding of 2*pi.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -228,11 +229,33 @@ def test_bin_slices_stable_and_exact():
     assert np.array_equal(perm, p_ref)                             # same members, same order
     assert np.array_equal(x, pts[perm, 0]) and np.array_equal(y, pts[perm, 1])
     assert off[-1] > np.count_nonzero((pts[:, 2] >= lo[0]) & (pts[:, 2] <= hi[-1]))
-    # many windows, few points each; and one window only
+    # many windows, few points each (in one pass, then through groups of 256 windows); and one window only
     zc, lo, hi = R.slice_windows(0.0, 114.0, 0.01)
-    off, x, y, perm = F.bin_slices(pts[:50_000], lo, hi)
     o_ref, p_ref = N.bin_slices(pts[:50_000], lo, hi)
-    assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
+    for two_level_from in ("-1", "0"):
+        os.environ["PCFIT_BIN_TWO_LEVEL_MIN"] = two_level_from
+        try:
+            off, x, y, perm = F.bin_slices(pts[:50_000], lo, hi)
+            assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
+            assert np.array_equal(x, pts[perm, 0]) and np.array_equal(y, pts[perm, 1])
+            off, x2, y2, none = F.bin_slices(pts[:50_000], lo, hi, want_perm=False)
+            assert none is None and np.array_equal(off, o_ref) and np.array_equal(x2, x) and np.array_equal(y2, y)
+            # 700 windows that share edges, z on a grid that hits them: the groups share edges as well
+            q = pts[:200_000].copy()
+            q[:, 2] = np.round(q[:, 2] * 8.0) / 8.0
+            qlo = 0.125 * np.arange(700)
+            off, x, y, perm = F.bin_slices(q, qlo, qlo + 0.125)
+            oq, pq = N.bin_slices(q, qlo, qlo + 0.125)
+            assert np.array_equal(off, oq) and np.array_equal(perm, pq)
+            assert np.array_equal(x, q[perm, 0]) and np.array_equal(y, q[perm, 1])
+            # outputs too small: the call says how many points there are and writes none
+            qhi, o_, x_, y_, t_ = qlo + 0.125, np.zeros(701, np.int64), np.zeros(10), np.zeros(10), np.zeros(1, np.int64)
+            with pytest.raises(F.PcfitError, match="outputs hold"):
+                F.check(F.lib().pcfit_bin_slices(F._p(q), len(q), F._p(qlo), F._p(qhi), 700, F._p(o_), F._p(x_),
+                                                 F._p(y_), None, 10, F._p(t_)))
+            assert t_[0] == oq[-1] and not x_.any()
+        finally:
+            del os.environ["PCFIT_BIN_TWO_LEVEL_MIN"]
     off, x, y, perm = F.bin_slices(pts, [10.0], [10.0])            # zero-width window
     assert np.array_equal(perm, np.nonzero(pts[:, 2] == 10.0)[0])
     # windows that share edges, z on a coarse grid: most points lie on an edge and belong to two windows
