@@ -14,7 +14,9 @@
 //            the scan) gives the output position.  No atomics, no inter-wave
 //            ordering: stable and deterministic by construction.  For up to
 //            256 windows the points go through LDS first (see
-//            bin_scatter_staged_kernel) so that the output is written in runs.
+//            bin_scatter_staged_kernel) so that the output is written in runs;
+//            the host-level calls bin more windows than that in two levels
+//            when the scan is large (bin_two_level).
 //
 // Windows are closed intervals that may share an edge, so a point can belong
 // to two consecutive windows (both get a copy) or to none.  Membership is

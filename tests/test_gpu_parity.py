@@ -689,6 +689,13 @@ def test_scan_sized_boundary_and_histogram_pass():
         o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
         assert np.array_equal(o["hist"], res["hist"][s])
         assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
+    # the 400 windows again through two groups of windows: the same bytes
+    os.environ["PCFIT_BIN_TWO_LEVEL_MIN"] = "0"
+    try:
+        off_b, x_b, y_b, _ = F.bin_slices(pts, lo, hi, want_perm=False)
+    finally:
+        del os.environ["PCFIT_BIN_TWO_LEVEL_MIN"]
+    assert np.array_equal(off_b, off) and np.array_equal(x_b, x) and np.array_equal(y_b, y)
     # the same scan in 200 windows of twice the width: up to 256 windows the scatter orders its tiles in LDS
     lo2, hi2 = lo[0::2], hi[1::2]
     off2, x2, y2, perm2 = F.bin_slices(pts, lo2, hi2)
