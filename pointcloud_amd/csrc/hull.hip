@@ -40,7 +40,9 @@
 
 namespace pcfit {
 
-constexpr int HULL_BLOCK = 1024;
+constexpr int HULL_BLOCK = 1024;          // threads of the wide launch (and the most a launch may have)
+constexpr int HULL_NARROW = 256;          // threads of the narrow launch for short filtered remainders
+#define HULL_NT ((int)blockDim.x)          // threads of this launch, in device code
 
 // Optional phase timing (tools only; -DPCFIT_PHASE_CLOCK): thread 0 of every workgroup adds the clocks
 // spent between marks to g_hull_phase[k].
@@ -60,6 +62,8 @@ __device__ unsigned long long g_hull_phase[8];
 #define HULL_MARK_INIT() do { } while (0)
 #endif
 constexpr int HULL_LDS_CAP = 8192;
+constexpr int HULL_SMALL_CAP = 2048;          // LDS capacity (points) of the narrow launch
+constexpr int64_t HULL_NARROW_MIN_SLICES = 512;   // fewer slices than this do not fill the chip either way
 
 __device__ __forceinline__ void two_sum(double a, double b, double &s, double &e)
 {
@@ -188,7 +192,7 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
             __syncthreads();
             return k;
         }
-        while ((L + c - 1) / c > HULL_BLOCK)
+        while ((L + c - 1) / c > HULL_NT)
             c <<= 1;
         const int kept = chain_chunk(px, py, list, L, c);
         const int64_t begin = (int64_t)threadIdx.x * c;
@@ -211,7 +215,7 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
             for (int i = 0; i < kept; i++)
                 pong[at + i] = (int64_t)list[begin + i];
             __syncthreads();
-            for (int64_t i = threadIdx.x; i < total; i += HULL_BLOCK)
+            for (int64_t i = threadIdx.x; i < total; i += HULL_NT)
                 list[i] = (IdxT)pong[i];
             __syncthreads();
         }
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     double *__restrict__ ux, double *__restrict__ uy, int64_t *__restrict__ n_unique, int64_t *__restrict__ hull_idx,
     int64_t *__restrict__ n_hull, int32_t *__restrict__ status, const int64_t *__restrict__ hull_start,
     double *__restrict__ wsx, double *__restrict__ wsy, uint32_t *__restrict__ wslist,
-    uint32_t *__restrict__ wspark, const HullSliceAux *__restrict__ aux, int hull_only)
+    uint32_t *__restrict__ wspark, const HullSliceAux *__restrict__ aux, int hull_only, int pass)
 {
     extern __shared__ double lds_dyn[];
     __shared__ double red[9 * 16];
@@ -422,6 +426,10 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
     if (IN_LDS ? (n > lds_cap) : (n <= lds_cap))
         return;                                          // the other launch takes this slice
+    // pass 1: the narrow launch, for what the filter left of long slices when that is short; pass 2: the wide
+    // launch that follows it and leaves those slices alone; pass 0: one launch for everything that fits the LDS
+    if (IN_LDS && ((pass == 1 && !filtered) || (pass == 2 && filtered && n <= HULL_SMALL_CAP)))
+        return;
     double *px, *py;
     IdxT *list;
     if constexpr (IN_LDS) {
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         status[s] = PCFIT_ST_OK;
     }
     if (IN_LDS || !filtered) {                           // (filtered and in global memory: already in place)
-        for (int64_t i = tid; i < n; i += HULL_BLOCK) {
+        for (int64_t i = tid; i < n; i += HULL_NT) {
             px[i] = src_x[i];
             py[i] = src_y[i];
         }
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         __shared__ int fcount, fdead;
         if (hull_only && !filtered && n > 1024) {
             double s1[2] = {0.0, 0.0};
-            for (int64_t i = tid; i < n; i += HULL_BLOCK) {
+            for (int64_t i = tid; i < n; i += HULL_NT) {
                 s1[0] += px[i];
                 s1[1] += py[i];
             }
@@ -524,7 +532,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         for (int ld = lk - 1; ld >= 0; ld--) {
             const uint32_t d = 1u << ld;
             const bool flip = ld == lk - 1;
-            for (uint32_t q = tid; q < half; q += HULL_BLOCK) {
+            for (uint32_t q = tid; q < half; q += HULL_NT) {
                 const uint32_t blk = q >> ld, o = q & (d - 1u);
                 uint32_t i, j;
                 if (flip) {
@@ -548,7 +556,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
 
     HULL_MARK(1);
     // ---- unique: keep the first of every run of equal rows
-    const int64_t per = (n + HULL_BLOCK - 1) / HULL_BLOCK;
+    const int64_t per = (n + HULL_NT - 1) / HULL_NT;
     const int64_t b0 = min(n, (int64_t)tid * per), b1 = min(n, b0 + per);
     int keep = 0;
     for (int64_t i = b0; i < b1; i++)
@@ -568,7 +576,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
     __syncthreads();
     const int64_t m = total_unique;
-    for (int64_t i = tid; i < m; i += HULL_BLOCK) {
+    for (int64_t i = tid; i < m; i += HULL_NT) {
         px[i] = ux[off + i];
         py[i] = uy[off + i];
     }
@@ -585,14 +593,14 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     // ---- rank check (circle_fitting.py:14-19)
     {
         double s1[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < m; i += HULL_BLOCK) {
+        for (int64_t i = tid; i < m; i += HULL_NT) {
             s1[0] += px[i];
             s1[1] += py[i];
         }
         block_sum<2>(s1, red);
         const double mx = s1[0] / (double)m, my = s1[1] / (double)m;
         double sc[3] = {0.0, 0.0, 0.0};
-        for (int64_t i = tid; i < m; i += HULL_BLOCK) {
+        for (int64_t i = tid; i < m; i += HULL_NT) {
             const double u = px[i] - mx, v = py[i] - my;
             sc[0] += u * u;
             sc[1] += u * v;
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         const double phi = 0.5 * atan2(2 * sc[1], sc[0] - sc[2]);
         const double c = cos(phi), sn = sin(phi);
         double pr[2] = {0.0, 0.0};
-        for (int64_t i = tid; i < m; i += HULL_BLOCK) {
+        for (int64_t i = tid; i < m; i += HULL_NT) {
             const double u = px[i] - mx, v = py[i] - my;
             const double a = c * u + sn * v, b = c * v - sn * u;
             pr[0] += a * a;
@@ -624,24 +632,24 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
 
     HULL_MARK(3);
     // ---- hull: lower chain (left to right), then upper chain (right to left)
-    for (int64_t i = tid; i < m; i += HULL_BLOCK)
+    for (int64_t i = tid; i < m; i += HULL_NT)
         list[i] = (IdxT)i;
     __syncthreads();
     const int64_t hl = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
     uint32_t *park = wspark + off;                      // the lower chain waits here
-    for (int64_t i = tid; i < hl - 1; i += HULL_BLOCK)
+    for (int64_t i = tid; i < hl - 1; i += HULL_NT)
         park[i] = (uint32_t)list[i];
     __syncthreads();
-    for (int64_t i = tid; i < m; i += HULL_BLOCK)
+    for (int64_t i = tid; i < m; i += HULL_NT)
         list[i] = (IdxT)(m - 1 - i);
     __syncthreads();
     const int64_t hu = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
     HULL_MARK(4);
     const int64_t h = (hl - 1) + (hu - 1);
     // both chains end on the other's first vertex: drop each chain's last entry
-    for (int64_t i = tid; i < hl - 1; i += HULL_BLOCK)
+    for (int64_t i = tid; i < hl - 1; i += HULL_NT)
         pong[i] = (int64_t)park[i];
-    for (int64_t i = tid; i < hu - 1; i += HULL_BLOCK)
+    for (int64_t i = tid; i < hu - 1; i += HULL_NT)
         pong[hl - 1 + i] = (int64_t)list[i];
     if (tid == 0) {
         n_hull[s] = h;
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     // optional rotation of the walk to a requested first vertex
     const int64_t want = hull_start && !filtered ? hull_start[s] : -1;
     if (want > 0) {
-        for (int64_t i = tid; i < h; i += HULL_BLOCK) {
+        for (int64_t i = tid; i < h; i += HULL_NT) {
             const int64_t v = pong[i];
             park[i] = (uint32_t)v;
             if (v == want)
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         __syncthreads();
         const int p0 = found_at;
         if (p0 != 0x7fffffff && p0 > 0) {
-            for (int64_t i = tid; i < h; i += HULL_BLOCK)
+            for (int64_t i = tid; i < h; i += HULL_NT)
                 pong[i] = (int64_t)park[(i + p0) % h];
         }
     }
@@ -767,13 +775,25 @@ int pcfit::unique_hull_dev(const double *x, const double *y, const int64_t *offs
     // more than 64 KB of dynamic LDS has to be granted explicitly (per device; idempotent)
     PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&unique_hull_kernel<true, uint16_t>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, HULL_LDS_CAP * 18));
+    int pass = 0;
+    if (aux && n_slices >= HULL_NARROW_MIN_SLICES) {
+        // What the filter left of a long slice is typically a few hundred points: a workgroup of 1024 threads
+        // spends its time in barriers on that, and only one of them fits a CU. With many slices a launch of
+        // 256-thread workgroups with a quarter of the LDS (four to a CU) takes the remainders that fit it first.
+        unique_hull_kernel<true, uint16_t><<<dim3((unsigned)n_slices), dim3(HULL_NARROW), (size_t)HULL_SMALL_CAP * 18,
+                                             st>>>(x, y, offsets, HULL_SMALL_CAP, ux, uy, n_unique, hull_idx, n_hull,
+                                                   status, hull_start, wsx, wsy, wslist, wspark, aux, hull_only, 1);
+        PCFIT_LAUNCH_CHECK();
+        pass = 2;
+    }
     unique_hull_kernel<true, uint16_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), lds, st>>>(
         x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux,
-        hull_only);
+        hull_only, pass);
     PCFIT_LAUNCH_CHECK();
     if (max_slice_len > cap) {
         unique_hull_kernel<false, uint32_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), 0, st>>>(
-            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux, 0);
+            x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux, 0,
+            0);
         PCFIT_LAUNCH_CHECK();
     }
     return PCFIT_OK;

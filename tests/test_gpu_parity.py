@@ -641,6 +641,47 @@ def test_unique_hull_on_slices_longer_than_lds():
         assert np.array_equal(hy["mask"][c0:c1], ref["inlier_mask"])
 
 
+def test_many_long_slices_take_the_narrow_hull_launch():
+    """From 512 slices on, what the sector filter leaves of a long slice goes to a launch of 256-thread workgroups
+    when it is short: the same kept points, hull vertices and order as the 1024-thread launch that smaller batches
+    use, and as the CPU hull on sampled slices. One slice keeps more than the narrow launch holds (an open arc is
+    not filtered), two are shorter than the LDS and never filtered."""
+    gen = np.random.default_rng(77)
+    sets = []
+    for s in range(520):
+        n = 8300 + int(gen.integers(0, 400))
+        th = gen.uniform(0, 2 * np.pi, n)
+        rr = 10.0 + gen.normal(0, 0.05, n)
+        bad = gen.random(n) < 0.03
+        rr[bad] = gen.uniform(0, 14.0, int(bad.sum()))
+        sets.append(np.stack([3 + rr * np.cos(th), -2 + rr * np.sin(th)], 1))
+    th = gen.uniform(0, 1.2 * np.pi, 9000)
+    sets[100] = np.stack([3 + 10 * np.cos(th), -2 + 10.2 * np.sin(th)], 1)      # open arc: nothing dropped
+    sets[7] = sets[7][:900]
+    sets[300] = sets[300][:5000]
+    x, y, off = csr(sets)
+    h = F.unique_hull_batch(x, y, off)
+    for a, b in ((0, 260), (260, 520)):                         # the same slices in batches below the threshold
+        xs, ys, offs = csr(sets[a:b])
+        g = F.unique_hull_batch(xs, ys, offs)
+        assert np.array_equal(g["n_unique"], h["n_unique"][a:b]) and np.array_equal(g["n_hull"], h["n_hull"][a:b])
+        assert np.array_equal(g["status"], h["status"][a:b])
+        for s in range(a, b):
+            o, og = off[s], offs[s - a]
+            nu, nh = int(h["n_unique"][s]), int(h["n_hull"][s])
+            assert np.array_equal(h["ux"][o:o + nu], g["ux"][og:og + nu]), s
+            assert np.array_equal(h["uy"][o:o + nu], g["uy"][og:og + nu]), s
+            assert np.array_equal(h["hull_idx"][o:o + nh], g["hull_idx"][og:og + nh]), s
+    assert h["n_unique"][100] == len(R.unique_rows(sets[100])) > 2048
+    assert np.median(h["n_unique"]) < 2048
+    for s in (0, 7, 100, 300, 519):
+        uniq = R.unique_rows(sets[s])
+        o = off[s]
+        nu, nh = int(h["n_unique"][s]), int(h["n_hull"][s])
+        kept = np.stack([h["ux"][o:o + nu], h["uy"][o:o + nu]], 1)
+        assert np.array_equal(kept[h["hull_idx"][o:o + nh]], uniq[N.hull(uniq)]), s
+
+
 def test_one_million_point_scan_through_the_analyzer():
     """The reference's own CPU-runnable case: 1 M points, 200 windows; five windows replayed on the CPU."""
     from pointcloud_amd import Config, CylinderAnalyzer

@@ -1,7 +1,6 @@
 #!/bin/bash
-set -e
-R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/c4r
-cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/c4r/trace -o s --output-format csv -- python3 $R/tools/exp_resident.py 100000000 2000 > $R/gpurun_out/c4r/log.txt 2>&1
-tail -1 $R/gpurun_out/c4r/log.txt
+mkdir -p gpurun_out
+timeout -k 10 500 python3 tools/exp_resident.py 100000000 2000 2>&1 | tail -1 || exit 1
+timeout -k 10 500 python3 tools/exp_resident.py 50000000 1000 2>&1 | tail -1 || exit 1
+timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 200 --timeout-method thread > gpurun_out/gpu_tests.txt 2>&1 || { tail -30 gpurun_out/gpu_tests.txt; exit 1; }
+tail -2 gpurun_out/gpu_tests.txt
