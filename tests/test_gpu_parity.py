@@ -846,6 +846,24 @@ def test_resident_scan_gives_the_same_analysis():
         CylinderAnalyzer(Config(z_min=1.0, z_max=9.0)).analyze_with_progress(DeviceScan(pts))
 
 
+def test_batch_of_scans_in_one_process():
+    """analyze_scans_sharded without a process group: the caller takes every scan, arrays or loaders alike, the
+    next upload overlapped with the current analysis; results equal the plain loop."""
+    from pointcloud_amd import Config, CylinderAnalyzer, sharding
+    from pointcloud_amd.synth import make_cylinder
+    az = CylinderAnalyzer(Config(min_points_per_slice=500))
+    scans = [make_cylinder(60_000, 10, seed=300 + k, outlier_frac=0.02) for k in range(4)]
+    seen = []
+    got = sharding.analyze_scans_sharded(az, [scans[0], lambda: scans[1], scans[2], lambda: scans[3]],
+                                         progress_callback=seen.append)
+    assert seen == [25, 50, 75, 100]
+    for k in range(4):
+        assert got[k] == az.analyze_with_progress(scans[k])
+    assert sharding.analyze_scans_sharded(az, []) == []
+    with pytest.raises(ValueError, match="Nx3"):
+        sharding.analyze_scans_sharded(az, [np.zeros((5, 2))])
+
+
 def test_hybrid_with_all_points_as_candidates_in_a_large_batch():
     """use_hull_vertices_only=False on 40 slices of 8000 points: 320 000 candidates come back (the results
     then leave the device section by section); three slices are compared with the same call on the slice alone."""
