@@ -188,6 +188,22 @@ int pcfit_ransac_batch_dev(const double *x, const double *y, const int64_t *offs
                            int32_t *best_trial, uint8_t *mask, int32_t *status, void *workspace,
                            size_t workspace_bytes, void *stream);
 
+/* pcfit_ransac_batch_dev without a workspace argument, for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * per-slice scratch (8 bytes per slice) lives in a fixed array inside the
+ * library's device image, PCFIT_RANSAC_STATIC_MAX_SLICES entries = 512 KB on
+ * every GPU the library runs on, held until the process ends; more slices than
+ * that give PCFIT_ERR_UNSUPPORTED.  The call allocates and frees nothing.  All
+ * calls on one GPU share that array: two calls that overlap in time on the same
+ * GPU (different streams or threads) race; calls on one stream, or on different
+ * GPUs, do not.  Same results as pcfit_ransac_batch_dev. */
+#define PCFIT_RANSAC_STATIC_MAX_SLICES 65536
+int pcfit_ransac_batch_static_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                  double inlier_tol, int32_t trials, double min_inliers_frac, const double *r_range,
+                                  const int32_t *triples, const int32_t *table_of_slice, double *model,
+                                  int32_t *score, int32_t *best_trial, uint8_t *mask, int32_t *status, void *stream);
+
 /* ---- residual profile + histogram: gui.py:972-987, analyzer.py:83-92 -- */
 /* Per point theta = (atan2 + 2pi) mod 2pi, dr = hypot - R and radius = hypot
  * (each output nullable); per slice numpy.histogram(dr, bins=H, range=(edges[0], edges[H]))

@@ -66,6 +66,8 @@ SIGNATURES = {
     "pcfit_ransac_workspace_bytes": (_sz, [_i64]),
     "pcfit_ransac_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                          _vp, _vp, _sz, _vp]),
+    "pcfit_ransac_batch_static_dev": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _vp]),
     "pcfit_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_angle_max_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp]),
     "pcfit_unique_hull_workspace_bytes": (_sz, [_i64, _i64]),

@@ -19,6 +19,8 @@
 // independent integer maximum, so the cross-workgroup combine is one 64-bit
 // atomicMax per workgroup and the result is deterministic.  A second small
 // kernel rebuilds the winning circle and writes the inlier mask.
+#include <mutex>
+
 #include "pcfit_internal.h"
 
 namespace pcfit {
@@ -274,27 +276,13 @@ PCFIT_API size_t pcfit_ransac_workspace_bytes(int64_t n_slices)
     return (size_t)(n_slices > 0 ? n_slices : 1) * sizeof(unsigned long long);
 }
 
-PCFIT_API int pcfit_ransac_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
-                                     double inlier_tol, int32_t trials, double min_inliers_frac,
-                                     const double *r_range, const int32_t *triples, const int32_t *table_of_slice,
-                                     double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
-                                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+// Both entry points below: argument checks, then clear the per-slice best keys and run the two kernels.
+static int ransac_enqueue(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double inlier_tol,
+                          int32_t trials, double min_inliers_frac, const double *r_range, const int32_t *triples,
+                          const int32_t *table_of_slice, double *model, int32_t *score, int32_t *best_trial,
+                          uint8_t *mask, int32_t *status, unsigned long long *best, hipStream_t st)
 {
-    PCFIT_ENTER();
-    PCFIT_REQUIRE(trials >= 0, "ransac: trials negative");
     const int64_t tiles = (trials + RS_BLOCK - 1) / RS_BLOCK;
-    PCFIT_REQUIRE(n_slices >= 0 && n_slices * (tiles > 0 ? tiles : 1) < (1ll << 31),
-                  "ransac: n_slices * ceil(trials/256) must stay below 2^31");
-    if (n_slices == 0)
-        return PCFIT_OK;
-    PCFIT_REQUIRE(x && y && offsets && model && score && best_trial && mask && status, "ransac: null pointer");
-    PCFIT_REQUIRE(trials == 0 || (triples && table_of_slice), "ransac: null sampling table");
-    if (!workspace || workspace_bytes < pcfit_ransac_workspace_bytes(n_slices)) {
-        set_error("ransac: workspace of %zu bytes needed", pcfit_ransac_workspace_bytes(n_slices));
-        return PCFIT_ERR_WORKSPACE;
-    }
-    hipStream_t st = as_stream(stream);
-    unsigned long long *best = static_cast<unsigned long long *>(workspace);
     PCFIT_HIP(hipMemsetAsync(best, 0, (size_t)n_slices * sizeof(unsigned long long), st));
     if (trials > 0) {
         dim3 grid((unsigned)(n_slices * tiles));
@@ -308,4 +296,90 @@ PCFIT_API int pcfit_ransac_batch_dev(const double *x, const double *y, const int
                        status);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
+}
+
+static int ransac_check_args(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, int32_t trials,
+                             const int32_t *triples, const int32_t *table_of_slice, double *model, int32_t *score,
+                             int32_t *best_trial, uint8_t *mask, int32_t *status)
+{
+    PCFIT_REQUIRE(trials >= 0, "ransac: trials negative");
+    const int64_t tiles = (trials + RS_BLOCK - 1) / RS_BLOCK;
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices * (tiles > 0 ? tiles : 1) < (1ll << 31),
+                  "ransac: n_slices * ceil(trials/256) must stay below 2^31");
+    if (n_slices == 0)
+        return PCFIT_OK;
+    PCFIT_REQUIRE(x && y && offsets && model && score && best_trial && mask && status, "ransac: null pointer");
+    PCFIT_REQUIRE(trials == 0 || (triples && table_of_slice), "ransac: null sampling table");
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_ransac_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                     double inlier_tol, int32_t trials, double min_inliers_frac,
+                                     const double *r_range, const int32_t *triples, const int32_t *table_of_slice,
+                                     double *model, int32_t *score, int32_t *best_trial, uint8_t *mask,
+                                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    PCFIT_ENTER();
+    PCFIT_TRY(ransac_check_args(x, y, offsets, n_slices, trials, triples, table_of_slice, model, score, best_trial,
+                                mask, status));
+    if (n_slices == 0)
+        return PCFIT_OK;
+    if (!workspace || workspace_bytes < pcfit_ransac_workspace_bytes(n_slices)) {
+        set_error("ransac: workspace of %zu bytes needed", pcfit_ransac_workspace_bytes(n_slices));
+        return PCFIT_ERR_WORKSPACE;
+    }
+    return ransac_enqueue(x, y, offsets, n_slices, inlier_tol, trials, min_inliers_frac, r_range, triples,
+                          table_of_slice, model, score, best_trial, mask, status,
+                          static_cast<unsigned long long *>(workspace), as_stream(stream));
+}
+
+// ---- the same call for callers that may not allocate and bring no workspace --------------------------
+// The per-slice best keys (the only scratch the two kernels use) live in an array that is part of the
+// library's device image: every GPU the library runs on holds its own copy at its own address until the
+// process ends.  In host code the array's name is not a device address; the address on the current device
+// is asked for once per device (hipGetSymbolAddress) and kept.
+namespace {
+constexpr int64_t RS_STATIC_SLICES = PCFIT_RANSAC_STATIC_MAX_SLICES;     // 512 KB per GPU
+static __device__ __align__(256) unsigned long long scratch[RS_STATIC_SLICES];
+constexpr int RS_MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned long long *g_scratch_ptr[RS_MAX_DEVICES] = {nullptr};
+
+int ransac_scratch(unsigned long long **out)
+{
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    PCFIT_REQUIRE(dev >= 0 && dev < RS_MAX_DEVICES, "ransac: device ordinal %d beyond %d", dev, RS_MAX_DEVICES);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        PCFIT_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        PCFIT_REQUIRE(p != nullptr, "ransac: the scratch array has no address on device %d", dev);
+        g_scratch_ptr[dev] = static_cast<unsigned long long *>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return PCFIT_OK;
+}
+}  // namespace
+
+PCFIT_API int pcfit_ransac_batch_static_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                            double inlier_tol, int32_t trials, double min_inliers_frac,
+                                            const double *r_range, const int32_t *triples,
+                                            const int32_t *table_of_slice, double *model, int32_t *score,
+                                            int32_t *best_trial, uint8_t *mask, int32_t *status, void *stream)
+{
+    PCFIT_ENTER();
+    PCFIT_TRY(ransac_check_args(x, y, offsets, n_slices, trials, triples, table_of_slice, model, score, best_trial,
+                                mask, status));
+    if (n_slices == 0)
+        return PCFIT_OK;
+    if (n_slices > RS_STATIC_SLICES) {
+        set_error("ransac (static scratch): at most %lld slices per call, got %lld; use pcfit_ransac_batch_dev with a "
+                  "workspace", (long long)RS_STATIC_SLICES, (long long)n_slices);
+        return PCFIT_ERR_UNSUPPORTED;
+    }
+    unsigned long long *best = nullptr;
+    PCFIT_TRY(ransac_scratch(&best));
+    return ransac_enqueue(x, y, offsets, n_slices, inlier_tol, trials, min_inliers_frac, r_range, triples,
+                          table_of_slice, model, score, best_trial, mask, status, best, as_stream(stream));
 }
