@@ -222,7 +222,8 @@ int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *o
 
 /* ---- unique rows, rank check, hull: circle_fitting.py:14-19, 182-198 -- */
 /* ux, uy: the slice's distinct points sorted by (x, y), written at the slice's
- * own CSR offset; n_unique[s] of them.  hull_idx (same CSR capacity): indices
+ * own CSR offset; n_unique[s] of them (all of them, whatever the slice's
+ * length: slices beyond 8192 points are sorted through the workspace).  hull_idx (same CSR capacity): indices
  * into the slice's unique array of its strictly convex hull, counter-
  * clockwise, starting at index 0 or, when hull_start (nullable, S entries,
  * -1 = default) names a hull vertex, at that vertex.  n_hull[s] = 0 and
@@ -239,10 +240,22 @@ int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t 
  * slice or a NaN circle).  dev_uniform (nullable): row s holds the deviation
  * profile resampled on K_s = max(1024, n_s) uniform angles, NaN from K_s to the
  * end of the row; rows are grid_len apart, grid_len >= max(1024, longest slice).
- * Slices of at most 8192 points. */
+ * Slices of at most 8192 points (PCFIT_ERR_UNSUPPORTED beyond). */
 int pcfit_ovality_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                             int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
                             int64_t grid_len, void *stream);
+/* The same for slices of any length (the reference takes any: with
+ * use_hull_vertices_only=False the candidates are all distinct points of the
+ * slice, circle_fitting.py:196-198).  Slices of up to 8192 points run as above;
+ * longer ones sort their angles through the workspace
+ * (pcfit_ovality_workspace_bytes(total_points, n_slices) bytes of device memory,
+ * not needed - may be NULL - when max_slice_len <= 8192).
+ * total_points = offsets[n_slices]. */
+size_t pcfit_ovality_workspace_bytes(int64_t total_points, int64_t n_slices);
+int pcfit_ovality_long_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                           int64_t total_points, int64_t max_slice_len, const double *cxcyr, double *scal,
+                           double *dev_uniform, int64_t grid_len, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* ---- host-pointer convenience forms (numpy in, numpy out) ------------ */
 int pcfit_kasa_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double *cxcyr,
@@ -288,10 +301,13 @@ int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, u
  *     to start from - lets a caller replay Qhull's order).
  * Out (capacity of every per-point array = offsets[S]):
  *     status S (0 ok / 1 / 2 / 3: the reference returns None), fit S*3,
- *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy); ux and uy may be NULL
- *                                when the caller does not want them: with hull candidates the
- *                                hull kernel then drops provably interior points of slices
- *                                longer than 1024 before sorting, and n_unique counts what it kept,
+ *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy), all of them for
+ *                                slices of any length; ux and uy may be NULL when the caller
+ *                                does not want them: with hull candidates (and no hull_start)
+ *                                the hull kernel then drops provably interior points of slices
+ *                                longer than 1024 before sorting, and n_unique counts what it
+ *                                kept; with use_hull = 0 the candidates are all distinct points
+ *                                and n_unique counts them either way,
  *     cand_offsets S+1, cand_x, cand_y, mask     candidates_xy and inlier_mask,
  *     radius, theta              hypot and angle of every candidate about the fit,
  *     argmax_argmin S*2          candidate indices of the largest / smallest radius,

@@ -412,6 +412,51 @@ def filtered_residual_profile(xy, cx, cy, rad, inlier_mask=None):
     return np.degrees(theta[order]), delta_r[order], valid
 
 
+def residual_profile_at_z(points_xyz, res_fit, z_elevation, z_tolerance, use_hull_vertices=True, hull_start=None):
+    """Profile delta_r(theta) of one z window about a fitted circle, over the hull
+    vertices of the window's distinct points or over all of them.  1.py:301-345.
+    ``hull_start`` replays Qhull's first vertex (the walk otherwise starts at the
+    lexicographic minimum; after the ordering by theta it only matters for ties)."""
+    cx, cy, rad = float(res_fit["center_x"]), float(res_fit["center_y"]), float(res_fit["radius"])
+    z = points_xyz[:, 2]
+    keep = (z >= z_elevation - z_tolerance) & (z <= z_elevation + z_tolerance)
+    if not np.any(keep):
+        return None
+    xy = points_xyz[keep, :2].astype(float, copy=False)
+    if xy.shape[0] < 3:
+        return None
+    xy = unique_rows(xy)
+    used = xy
+    if use_hull_vertices and has_2d_variation(xy):
+        verts = hull_ccw(xy)
+        if hull_start is not None:
+            verts = rotate_to(verts, hull_start)
+        if verts.size >= 3:
+            used = xy[verts]
+    ex = used[:, 0] - cx
+    ey = used[:, 1] - cy
+    theta = (np.arctan2(ey, ex) + 2 * np.pi) % (2 * np.pi)
+    delta_r = np.hypot(ex, ey) - rad
+    order = np.argsort(theta)
+    return {"theta": theta[order], "delta_r": delta_r[order], "xy_used": used[order], "cx": cx, "cy": cy, "R": rad}
+
+
+def make_slab(n, seed, outlier=0.0, dup=0, sigma=0.05, half_height=0.9):
+    """(n + dup, 3) points of a noisy ring (radius 10 about (3, -2)) with z uniform in +-half_height;
+    ``dup`` of the points appear twice.  Input generator of the long-slice fixtures."""
+    g = np.random.default_rng(seed)
+    th = g.uniform(0.0, 2 * np.pi, n)
+    rr = 10.0 + g.normal(0, sigma, n)
+    if outlier > 0:
+        bad = g.random(n) < outlier
+        rr[bad] = g.uniform(0, 14.0, int(bad.sum()))
+    xy = np.stack([3.0 + rr * np.cos(th), -2.0 + rr * np.sin(th)], axis=1)
+    if dup:
+        xy = np.concatenate([xy, xy[g.integers(0, n, dup)]])
+    z = g.uniform(-half_height, half_height, len(xy))
+    return np.column_stack([xy, z])
+
+
 def residual_histogram(delta_r, bins, lo, hi):
     """Counts of delta_r over ``bins`` equal bins on [lo, hi]: half-open bins,
     last bin closed, values outside dropped (numpy.histogram semantics).  Not in

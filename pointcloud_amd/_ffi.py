@@ -74,6 +74,8 @@ SIGNATURES = {
     "pcfit_unique_hull_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                               _vp]),
     "pcfit_ovality_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    "pcfit_ovality_workspace_bytes": (_sz, [_i64, _i64]),
+    "pcfit_ovality_long_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _vp, _sz, _vp]),
     "pcfit_kasa_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "pcfit_lm_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp]),
     "pcfit_ransac_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _u64, _vp, _vp, _vp, _vp, _vp]),
@@ -296,7 +298,7 @@ def circle3_batch(triples):
     return out, ok.astype(bool)
 
 
-OV_CAP = 8192          # most candidates per slice the ovality kernel takes (pipeline.hip)
+OV_CAP = 8192          # candidates per slice that the ovality kernel holds in LDS (pipeline.hip); more go through a workspace
 
 
 def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
@@ -315,7 +317,10 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
     radius, theta = np.zeros(tot), np.zeros(tot)
     amm = np.zeros((S, 2), np.int64)
     ov = np.zeros((S, 5))
-    K = int(max(1024, min(OV_CAP, np.diff(offsets).max() if S else 0)))
+    # rows of the resampled profile: as long as the longest candidate list can get (hull candidates beyond
+    # OV_CAP vertices are refused by the library when a profile is wanted)
+    longest = int(np.diff(offsets).max()) if S else 0
+    K = int(max(1024, min(OV_CAP, longest) if use_hull else longest))
     dev = np.full((S, K), np.nan) if want_profile else None
     rr = None if r_range is None else _arr(r_range, np.float64)
     hs = None if hull_start is None else _arr(hull_start, np.int64)

@@ -30,9 +30,12 @@
 // sector, so it does not matter where inside the outline the centroid lies.
 // For a noisy ring that leaves a few percent of the points.  The filter runs
 // one workgroup per 8192 points; what it keeps is then sorted, made unique and
-// hulled as before, so hull vertices and their order are unchanged, while
-// n_unique / ux / uy of such a slice describe the kept points only and a
-// requested start vertex (an index into the full unique set) is not honoured.
+// hulled as before, so hull vertices and their order are unchanged.  A caller
+// that wants the hulls only (hull_only) stops there: n_unique / ux / uy of such
+// a slice then describe the kept points.  Otherwise the whole slice is sorted
+// and made unique as well (longsort.hip: tile sort in LDS, rank merges in global
+// memory), the hull vertices are looked up in that full sorted set by their
+// coordinates, and a requested start vertex is honoured.
 #include <algorithm>
 
 #include "pcfit_internal.h"
@@ -677,23 +680,86 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
 // Workspace: wsx, wsy (8 B per point each), wslist, wspark (4 B each), then - for batches of at most
 // HULL_FILTER_MAX_SLICES slices - the filter's segment table, partial sums and per-slice records.
 struct HullLayout {
-    size_t total, seg_off, part_off, aux_off, bytes;
+    size_t total, seg_off, part_off, aux_off, b1_off, hc_off, ls_off, bytes;
     int64_t max_segs;
-    bool filter;
+    bool filter, full;
 };
 
-static HullLayout hull_layout(size_t total, int64_t S)
+// full: room for the sort of whole long slices as well (a second buffer pair, the hull vertices' coordinates
+// and the tile tables of longsort.hip)
+static HullLayout hull_layout(size_t total, int64_t S, bool full)
 {
     HullLayout l;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     l.total = total;
     l.filter = S <= HULL_FILTER_MAX_SLICES;
+    l.full = full && l.filter;
     l.max_segs = (int64_t)(total / SPLIT_SEG) + S + 1;
     l.seg_off = up(total * 24 + 1024);
     l.part_off = l.seg_off + (l.filter ? up((size_t)(S + 2) * 8) : 0);
     l.aux_off = l.part_off + (l.filter ? up((size_t)l.max_segs * SPLIT_PART * 8) : 0);
-    l.bytes = l.aux_off + (l.filter ? up((size_t)std::max<int64_t>(S, 1) * sizeof(HullSliceAux)) : 0);
+    l.b1_off = l.aux_off + (l.filter ? up((size_t)std::max<int64_t>(S, 1) * sizeof(HullSliceAux)) : 0);
+    l.hc_off = l.b1_off + (l.full ? up(total * 16) : 0);
+    l.ls_off = l.hc_off + (l.full ? up(total * 16) : 0);
+    l.bytes = l.ls_off + (l.full ? long_sort_workspace_bytes((int64_t)total, S) : 0);
     return l;
+}
+
+// Filtered long slices, when the caller wants every distinct point: the coordinates of the hull vertices are
+// set aside before the full distinct set replaces the kept one in ux / uy ...
+__global__ __launch_bounds__(256) void hull_coords_kernel(const int64_t *__restrict__ offsets,
+                                                         const HullSliceAux *__restrict__ aux,
+                                                         const double *__restrict__ ux, const double *__restrict__ uy,
+                                                         const int64_t *__restrict__ hull_idx,
+                                                         const int64_t *__restrict__ n_hull, double *__restrict__ hcx,
+                                                         double *__restrict__ hcy)
+{
+    const int64_t s = blockIdx.x;
+    if (aux[s].filtered != 1)
+        return;
+    const int64_t off = offsets[s], h = n_hull[s];
+    for (int64_t i = threadIdx.x; i < h; i += 256) {
+        const int64_t v = hull_idx[off + i];
+        hcx[off + i] = ux[off + v];
+        hcy[off + i] = uy[off + v];
+    }
+}
+
+// ... and looked up in it afterwards (binary search by coordinates: every vertex is one of the distinct
+// points), followed by the optional rotation of the walk to a requested first vertex.
+__global__ __launch_bounds__(256) void hull_remap_kernel(const int64_t *__restrict__ offsets,
+                                                        const HullSliceAux *__restrict__ aux,
+                                                        const double *__restrict__ ux, const double *__restrict__ uy,
+                                                        const int64_t *__restrict__ n_unique,
+                                                        const int64_t *__restrict__ n_hull, double *__restrict__ hcx,
+                                                        const double *__restrict__ hcy, int64_t *__restrict__ hull_idx,
+                                                        const int64_t *__restrict__ hull_start)
+{
+    __shared__ int found_at;
+    const int64_t s = blockIdx.x;
+    if (aux[s].filtered != 1)
+        return;
+    const int64_t off = offsets[s], h = n_hull[s], m = n_unique[s];
+    const int64_t want = hull_start ? hull_start[s] : -1;
+    if (threadIdx.x == 0)
+        found_at = 0x7fffffff;
+    __syncthreads();
+    long long *found = reinterpret_cast<long long *>(hcx + off);       // the x coordinate's slot takes the index
+    for (int64_t i = threadIdx.x; i < h; i += 256) {
+        const double vx = hcx[off + i], vy = hcy[off + i];
+        int64_t lo = 0, hi = m;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (lex_less(ux[off + mid], uy[off + mid], vx, vy)) lo = mid + 1; else hi = mid;
+        }
+        found[i] = lo;
+        if (lo == want)
+            atomicMin(&found_at, (int)i);
+    }
+    __syncthreads();
+    const int p0 = (want > 0 && found_at != 0x7fffffff) ? found_at : 0;
+    for (int64_t i = threadIdx.x; i < h; i += 256)
+        hull_idx[off + i] = found[(i + p0) % h];
 }
 
 }  // namespace pcfit
@@ -702,7 +768,12 @@ using namespace pcfit;
 
 PCFIT_API size_t pcfit_unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices)
 {
-    return hull_layout((size_t)(total_points > 0 ? total_points : 1), std::max<int64_t>(n_slices, 0)).bytes;
+    return hull_layout((size_t)(total_points > 0 ? total_points : 1), std::max<int64_t>(n_slices, 0), true).bytes;
+}
+
+size_t pcfit::unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices, int hull_only)
+{
+    return hull_layout((size_t)(total_points > 0 ? total_points : 1), std::max<int64_t>(n_slices, 0), !hull_only).bytes;
 }
 
 PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
@@ -717,8 +788,9 @@ PCFIT_API int pcfit_unique_hull_batch_dev(const double *x, const double *y, cons
 }
 
 // hull_only: the caller wants the hulls and no list of distinct points; slices of more than 1024 points then drop
-// their provably interior points before the sort, and ux / uy / n_unique describe what was kept (as they do for
-// slices beyond the LDS in any case); hull_start must be null.
+// their provably interior points before the sort, and ux / uy / n_unique describe what was kept; hull_start must
+// be null.  Otherwise ux / uy / n_unique are the distinct points of the whole slice, whatever its length.
+// The workspace is sized by unique_hull_workspace_bytes(total, n_slices, hull_only).
 int pcfit::unique_hull_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                            int64_t max_slice_len, double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx,
                            int64_t *n_hull, int32_t *status, const int64_t *hull_start, void *workspace,
@@ -733,19 +805,20 @@ int pcfit::unique_hull_dev(const double *x, const double *y, const int64_t *offs
                   "unique_hull: max_slice_len must be given (0..2^31-1)");
     // total points are not known here (offsets live on the device): the caller sized the workspace with
     // pcfit_unique_hull_workspace_bytes(total, n_slices); the largest total whose layout fits is the one
-    if (!workspace || workspace_bytes < hull_layout(1, n_slices).bytes) {
+    const bool full = !hull_only;
+    if (!workspace || workspace_bytes < hull_layout(1, n_slices, full).bytes) {
         set_error("unique_hull: workspace missing");
         return PCFIT_ERR_WORKSPACE;
     }
     size_t lo = 1, hi = workspace_bytes / 24;
     while (lo < hi) {
         const size_t mid = lo + (hi - lo + 1) / 2;
-        if (hull_layout(mid, n_slices).bytes <= workspace_bytes)
+        if (hull_layout(mid, n_slices, full).bytes <= workspace_bytes)
             lo = mid;
         else
             hi = mid - 1;
     }
-    const HullLayout l = hull_layout(lo, n_slices);
+    const HullLayout l = hull_layout(lo, n_slices, full);
     const size_t total = l.total;
     char *ws = static_cast<char *>(workspace);
     double *wsx = reinterpret_cast<double *>(ws);
@@ -794,6 +867,26 @@ int pcfit::unique_hull_dev(const double *x, const double *y, const int64_t *offs
         unique_hull_kernel<false, uint32_t><<<dim3((unsigned)n_slices), dim3(HULL_BLOCK), 0, st>>>(
             x, y, offsets, cap, ux, uy, n_unique, hull_idx, n_hull, status, hull_start, wsx, wsy, wslist, wspark, aux, 0,
             0);
+        PCFIT_LAUNCH_CHECK();
+    }
+    if (aux && l.full) {
+        // The filtered slices so far hold the distinct points of what the filter kept.  The caller wants all
+        // of them: set the hull vertices' coordinates aside, sort the whole slices (the kept points' buffers
+        // are free now and serve as one of the two buffer pairs), write the distinct points and look the
+        // vertices up again.
+        double *b1x = reinterpret_cast<double *>(ws + l.b1_off), *b1y = b1x + total;
+        double *hcx = reinterpret_cast<double *>(ws + l.hc_off), *hcy = hcx + total;
+        void *small = ws + l.ls_off;
+        const dim3 per_slice((unsigned)n_slices);
+        hull_coords_kernel<<<per_slice, dim3(256), 0, st>>>(offsets, aux, ux, uy, hull_idx, n_hull, hcx, hcy);
+        PCFIT_LAUNCH_CHECK();
+        int second = 0;
+        PCFIT_TRY(long_sort_dev(x, y, wsx, wsy, b1x, b1y, offsets, n_slices, (int64_t)total, max_slice_len, cap, small,
+                                &second, st));
+        PCFIT_TRY(long_unique_dev(second ? b1x : wsx, second ? b1y : wsy, offsets, n_slices, (int64_t)total,
+                                  max_slice_len, cap, small, ux, uy, n_unique, st));
+        hull_remap_kernel<<<per_slice, dim3(256), 0, st>>>(offsets, aux, ux, uy, n_unique, n_hull, hcx, hcy, hull_idx,
+                                                           hull_start);
         PCFIT_LAUNCH_CHECK();
     }
     return PCFIT_OK;

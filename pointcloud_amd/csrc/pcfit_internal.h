@@ -19,6 +19,17 @@ int bin_check_windows(const double *z_lo, const double *z_hi, int64_t n_slices, 
 int unique_hull_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, int64_t max_slice_len,
                     double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull, int32_t *status,
                     const int64_t *hull_start, void *workspace, size_t workspace_bytes, void *stream, int hull_only);
+size_t unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices, int hull_only);
+
+// longsort.hip: lexicographic sort of (a, b) pairs inside every slice longer than min_len, and the distinct
+// pairs of the sorted slices (see there)
+size_t long_sort_workspace_bytes(int64_t total, int64_t n_slices);
+int long_sort_dev(const double *in_a, const double *in_b, double *a0, double *b0, double *a1, double *b1,
+                  const int64_t *offsets, int64_t n_slices, int64_t total, int64_t max_len, int64_t min_len,
+                  void *small_ws, int *in_second, hipStream_t st);
+int long_unique_dev(const double *a, const double *b, const int64_t *offsets, int64_t n_slices, int64_t total,
+                    int64_t max_len, int64_t min_len, void *small_ws, double *ua, double *ub, int64_t *n_unique,
+                    hipStream_t st);
 
 #define PCFIT_HIP(call)                                                                       \
     do {                                                                                      \

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pcfit_internal.h"
+#include "segments.h"
 
 namespace pcfit {
 
@@ -143,6 +144,147 @@ __global__ __launch_bounds__(OV_BLOCK) void ovality_kernel(const double *__restr
         scal[5 * s + 3] = R > 0 ? 100.0 * (rmax - rmin) / R : qnan;
         scal[5 * s + 4] = sqrt(acc[0] * acc[0] + acc[1] * acc[1]) / ((double)K / 2.0);
     }
+}
+
+// ---- the same for candidate lists beyond the LDS (every distinct point of a long slice as candidates,
+// circle_fitting.py:196-198).  theta and the point's index (as a double: exact below 2^53) are sorted as
+// pairs by longsort.hip - ties by index, the rule of the kernel above -, then every tile of 8192 grid angles
+// of a slice is interpolated by its own workgroup (K = n for these slices) and the partial DFT sums and
+// extremes are combined per slice in tile order.
+__global__ __launch_bounds__(SPLIT_BLOCK) void ov_long_prepare_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, int64_t S,
+    const int64_t *__restrict__ segstart, int64_t min_len, const double *__restrict__ cxcyr,
+    double *__restrict__ th, double *__restrict__ id)
+{
+    SegRef r;
+    if (!find_segment(segstart, offsets, S, x, y, r))
+        return;
+    const int64_t off = offsets[r.slice];
+    if (offsets[r.slice + 1] - off <= min_len)
+        return;
+    const double cx = cxcyr[3 * r.slice], cy = cxcyr[3 * r.slice + 1];
+    for (int32_t i = threadIdx.x; i < r.n; i += SPLIT_BLOCK) {
+        th[off + r.first + i] = wrap_angle(r.ys[i] - cy, r.xs[i] - cx);
+        id[off + r.first + i] = (double)(r.first + i);
+    }
+}
+
+// part: 4 doubles per tile = {sum v cos, -sum v sin, rmax, rmin}
+__global__ __launch_bounds__(SPLIT_BLOCK) void ov_long_part_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, int64_t S,
+    const int64_t *__restrict__ segstart, int64_t min_len, const double *__restrict__ cxcyr,
+    const double *__restrict__ th_all, const double *__restrict__ id_all, double *__restrict__ part,
+    double *__restrict__ dev_uniform, int64_t grid_len)
+{
+    __shared__ double red[4 * 16];
+    SegRef r;
+    if (!find_segment(segstart, offsets, S, x, y, r))
+        return;
+    const int64_t off = offsets[r.slice], n = offsets[r.slice + 1] - off;
+    if (n <= min_len)
+        return;
+    const int64_t s = r.slice;
+    const double cx = cxcyr[3 * s], cy = cxcyr[3 * s + 1], R = cxcyr[3 * s + 2];
+    const double *th = th_all + off, *id = id_all + off, *xs = x + off, *ys = y + off;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    auto dev_at = [&](int64_t j) {
+        const int64_t src = (int64_t)id[j];
+        return cr_hypot(xs[src] - cx, ys[src] - cy) - R;
+    };
+    const int64_t K = n;                                   // max(1024, n) with n beyond the LDS capacity
+    const double step = TWO_PI / (double)K;
+    double acc[2] = {0.0, 0.0};
+    double rmax = -inf, rmin = inf;
+    for (int32_t i = threadIdx.x; i < r.n; i += SPLIT_BLOCK) {
+        const double rr = cr_hypot(r.xs[i] - cx, r.ys[i] - cy);
+        rmax = fmax(rmax, rr);
+        rmin = fmin(rmin, rr);
+        const int64_t k = r.first + i;
+        const double t = (double)k * step;
+        int64_t lo = -1, hi = n - 1;                       // largest j in [-1, n-1] with th[j] <= t
+        while (lo < hi) {
+            const int64_t mid = lo + (hi - lo + 1) / 2;
+            if (th[mid] <= t) lo = mid; else hi = mid - 1;
+        }
+        const int64_t j = lo;
+        const double xj = j < 0 ? th[n - 1] - TWO_PI : th[j];
+        const double fj = j < 0 ? dev_at(n - 1) : dev_at(j);
+        double v;
+        if (xj == t) {
+            v = fj;
+        } else {
+            const double xn = j + 1 < n ? th[j + 1] : th[0] + TWO_PI;
+            const double fn = j + 1 < n ? dev_at(j + 1) : dev_at(0);
+            const double slope = (fn - fj) / (xn - xj);
+            v = slope * (t - xj) + fj;
+        }
+        if (dev_uniform)
+            dev_uniform[s * grid_len + k] = v;
+        const double ang = 2.0 * TWO_PI * (double)k / (double)K;
+        acc[0] += v * cos(ang);
+        acc[1] -= v * sin(ang);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        rmax = fmax(rmax, __shfl_xor(rmax, m, WAVE));
+        rmin = fmin(rmin, __shfl_xor(rmin, m, WAVE));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[32 + (threadIdx.x >> 6)] = rmax;
+        red[48 + (threadIdx.x >> 6)] = rmin;
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        for (int w = 0; w < SPLIT_BLOCK / WAVE; w++) {
+            rmax = fmax(rmax, red[32 + w]);
+            rmin = fmin(rmin, red[48 + w]);
+        }
+        double *p = part + 4 * r.seg;
+        p[0] = acc[0];
+        p[1] = acc[1];
+        p[2] = rmax;
+        p[3] = rmin;
+    }
+}
+
+__global__ __launch_bounds__(WAVE) void ov_long_final_kernel(const int64_t *__restrict__ offsets,
+                                                            const int64_t *__restrict__ segstart, int64_t min_len,
+                                                            const double *__restrict__ cxcyr,
+                                                            const double *__restrict__ part, double *__restrict__ scal,
+                                                            double *__restrict__ dev_uniform, int64_t grid_len)
+{
+    const int64_t s = blockIdx.x;
+    const int64_t n = offsets[s + 1] - offsets[s];
+    if (n <= min_len)
+        return;
+    const double cx = cxcyr[3 * s], cy = cxcyr[3 * s + 1], R = cxcyr[3 * s + 2];
+    const double qnan = __longlong_as_double(0x7ff8000000000000ll);
+    if (dev_uniform)
+        for (int64_t k = n + threadIdx.x; k < grid_len; k += WAVE)
+            dev_uniform[s * grid_len + k] = qnan;
+    if (!(cx == cx) || !(cy == cy) || !(R == R)) {
+        if (threadIdx.x < 5)
+            scal[5 * s + threadIdx.x] = qnan;
+        if (dev_uniform)
+            for (int64_t k = threadIdx.x; k < n; k += WAVE)
+                dev_uniform[s * grid_len + k] = qnan;
+        return;
+    }
+    if (threadIdx.x != 0)
+        return;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double a0 = 0.0, a1 = 0.0, rmax = -inf, rmin = inf;
+    for (int64_t g = segstart[s]; g < segstart[s + 1]; g++) {
+        a0 += part[4 * g];
+        a1 += part[4 * g + 1];
+        rmax = fmax(rmax, part[4 * g + 2]);
+        rmin = fmin(rmin, part[4 * g + 3]);
+    }
+    scal[5 * s] = rmax;
+    scal[5 * s + 1] = rmin;
+    scal[5 * s + 2] = rmax - rmin;
+    scal[5 * s + 3] = R > 0 ? 100.0 * (rmax - rmin) / R : qnan;
+    scal[5 * s + 4] = sqrt(a0 * a0 + a1 * a1) / ((double)n / 2.0);
 }
 
 // circle_fitting.py:14-19 for m points at px, py (global memory), evaluated by a
@@ -291,6 +433,20 @@ int launch_fit(const double *x, const double *y, const int64_t *offsets, int64_t
 
 using namespace pcfit;
 
+static int ovality_lds_launch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                              int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
+                              int64_t grid_len, hipStream_t st)
+{
+    const int64_t longest = std::min<int64_t>(max_slice_len, OV_CAP);
+    const int cap = (int)std::max<int64_t>(64, (longest + 63) / 64 * 64);
+    PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ovality_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, OV_CAP * 18));
+    ovality_kernel<<<dim3((unsigned)n_slices), dim3(OV_BLOCK), (size_t)cap * 18, st>>>(x, y, offsets, cxcyr, cap, scal,
+                                                                                       dev_uniform, grid_len);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
 PCFIT_API int pcfit_ovality_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                       int64_t max_slice_len, const double *cxcyr, double *scal, double *dev_uniform,
                                       int64_t grid_len, void *stream)
@@ -302,17 +458,84 @@ PCFIT_API int pcfit_ovality_batch_dev(const double *x, const double *y, const in
     PCFIT_REQUIRE(x && y && offsets && cxcyr && scal, "ovality: null pointer");
     PCFIT_REQUIRE(max_slice_len >= 0, "ovality: max_slice_len must be given");
     if (max_slice_len > OV_CAP) {
-        set_error("ovality: slices of more than %d points are not supported (got %lld)", OV_CAP,
-                  (long long)max_slice_len);
+        set_error("ovality: slices of more than %d points (got %lld) need pcfit_ovality_long_dev and its workspace",
+                  OV_CAP, (long long)max_slice_len);
         return PCFIT_ERR_UNSUPPORTED;
     }
     PCFIT_REQUIRE(!dev_uniform || grid_len >= std::max<int64_t>(1024, max_slice_len),
                   "ovality: grid_len must be >= max(1024, longest slice)");
-    const int cap = (int)std::max<int64_t>(64, (max_slice_len + 63) / 64 * 64);
-    PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&ovality_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, OV_CAP * 18));
-    ovality_kernel<<<dim3((unsigned)n_slices), dim3(OV_BLOCK), (size_t)cap * 18, as_stream(stream)>>>(
-        x, y, offsets, cxcyr, cap, scal, dev_uniform, grid_len);
+    return ovality_lds_launch(x, y, offsets, n_slices, max_slice_len, cxcyr, scal, dev_uniform, grid_len,
+                              as_stream(stream));
+}
+
+namespace {
+struct OvLongLayout {
+    size_t b0_off, b1_off, part_off, ls_off, bytes;
+    int64_t max_segs;
+};
+OvLongLayout ov_long_layout(int64_t total, int64_t S)
+{
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    OvLongLayout l;
+    const size_t t = (size_t)std::max<int64_t>(total, 1);
+    l.max_segs = total / SPLIT_SEG + S + 1;
+    l.b0_off = 0;
+    l.b1_off = up(t * 16);
+    l.part_off = l.b1_off + up(t * 16);
+    l.ls_off = l.part_off + up((size_t)l.max_segs * 32);
+    l.bytes = l.ls_off + long_sort_workspace_bytes(total, S);
+    return l;
+}
+}  // namespace
+
+PCFIT_API size_t pcfit_ovality_workspace_bytes(int64_t total_points, int64_t n_slices)
+{
+    return ov_long_layout(std::max<int64_t>(total_points, 0), std::max<int64_t>(n_slices, 0)).bytes;
+}
+
+PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                     int64_t total_points, int64_t max_slice_len, const double *cxcyr, double *scal,
+                                     double *dev_uniform, int64_t grid_len, void *workspace, size_t workspace_bytes,
+                                     void *stream)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "ovality: n_slices out of range");
+    if (n_slices == 0)
+        return PCFIT_OK;
+    PCFIT_REQUIRE(x && y && offsets && cxcyr && scal, "ovality: null pointer");
+    PCFIT_REQUIRE(max_slice_len >= 0 && total_points >= max_slice_len, "ovality: max_slice_len / total_points must be given");
+    PCFIT_REQUIRE(!dev_uniform || grid_len >= std::max<int64_t>(1024, max_slice_len),
+                  "ovality: grid_len must be >= max(1024, longest slice)");
+    hipStream_t st = as_stream(stream);
+    // slices that fit the LDS (the kernel writes NaN for the longer ones, which the second step replaces)
+    PCFIT_TRY(ovality_lds_launch(x, y, offsets, n_slices, max_slice_len, cxcyr, scal, dev_uniform, grid_len, st));
+    if (max_slice_len <= OV_CAP)
+        return PCFIT_OK;
+    const OvLongLayout l = ov_long_layout(total_points, n_slices);
+    if (!workspace || workspace_bytes < l.bytes) {
+        set_error("ovality: workspace of %zu bytes needed", l.bytes);
+        return PCFIT_ERR_WORKSPACE;
+    }
+    PCFIT_REQUIRE(l.max_segs < (1ll << 31), "ovality: too many tiles");
+    char *ws = static_cast<char *>(workspace);
+    const size_t t = (size_t)total_points;
+    double *b0a = reinterpret_cast<double *>(ws + l.b0_off), *b0b = b0a + t;
+    double *b1a = reinterpret_cast<double *>(ws + l.b1_off), *b1b = b1a + t;
+    double *part = reinterpret_cast<double *>(ws + l.part_off);
+    int64_t *segstart = reinterpret_cast<int64_t *>(ws + l.ls_off);
+    const dim3 grid((unsigned)l.max_segs);
+    split_map_kernel<<<dim3(1), dim3(1024), 0, st>>>(offsets, n_slices, segstart);
+    ov_long_prepare_kernel<<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, n_slices, segstart, OV_CAP, cxcyr, b1a,
+                                                               b1b);
+    PCFIT_LAUNCH_CHECK();
+    int second = 0;
+    PCFIT_TRY(long_sort_dev(b1a, b1b, b0a, b0b, b1a, b1b, offsets, n_slices, total_points, max_slice_len, OV_CAP,
+                            ws + l.ls_off, &second, st));
+    ov_long_part_kernel<<<grid, dim3(SPLIT_BLOCK), 0, st>>>(x, y, offsets, n_slices, segstart, OV_CAP, cxcyr,
+                                                            second ? b1a : b0a, second ? b1b : b0b, part, dev_uniform,
+                                                            grid_len);
+    ov_long_final_kernel<<<dim3((unsigned)n_slices), dim3(WAVE), 0, st>>>(offsets, segstart, OV_CAP, cxcyr, part, scal,
+                                                                          dev_uniform, grid_len);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -371,8 +594,11 @@ PCFIT_API int pcfit_ovality_batch(const double *x, const double *y, const int64_
     PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
     PCFIT_TRY(dsc.alloc(n_slices * 40));
     if (dev_uniform) PCFIT_TRY(ddev.alloc((size_t)n_slices * grid_len * 8));
-    PCFIT_TRY(pcfit_ovality_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, max_len,
-                                      dfit.as<double>(), dsc.as<double>(), ddev.as<double>(), grid_len, st));
+    DevBuf dws;
+    if (max_len > OV_CAP) PCFIT_TRY(dws.alloc(pcfit_ovality_workspace_bytes(total, n_slices)));
+    PCFIT_TRY(pcfit_ovality_long_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices, total, max_len,
+                                     dfit.as<double>(), dsc.as<double>(), ddev.as<double>(), grid_len, dws.p,
+                                     dws.bytes, st));
     PCFIT_TRY(dsc.download(scal, n_slices * 40, st));
     if (dev_uniform) PCFIT_TRY(ddev.download(dev_uniform, (size_t)n_slices * grid_len * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
@@ -484,9 +710,9 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     int64_t *dnh = reinterpret_cast<int64_t *>(d1.as<char>() + nh_at);
     int32_t *dst1 = reinterpret_cast<int32_t *>(d1.as<char>() + st1_at);
     if (hull_start) PCFIT_TRY(dhs.upload(hull_start, S * 8, st));
-    PCFIT_TRY(dws.alloc(pcfit_unique_hull_workspace_bytes(total, S)));
     // hull candidates and nobody asks for the distinct points: the hull kernel may drop interior points first
     const int hull_only = (use_hull && !ux && !uy && !hull_start) ? 1 : 0;
+    PCFIT_TRY(dws.alloc(unique_hull_workspace_bytes(total, S, hull_only)));
     PCFIT_TRY(unique_hull_dev(dxp, dyp, doffp, S, max_len, dux.as<double>(), duy.as<double>(), dnu, dhi.as<int64_t>(),
                               dnh, dst1, dhs.as<int64_t>(), dws.p, dws.bytes, st, hull_only));
     hbuf.resize(d1_bytes);
@@ -603,7 +829,10 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     if (dev_uniform) PCFIT_TRY(ddev.alloc((size_t)S * grid_len * 8));
     PCFIT_TRY(pcfit_residuals_batch_dev(dcx, dcy, dco, S, dfit, dth, nullptr, drad, 0, nullptr, nullptr,
                                         drm.as<double>(), dam, st));
-    PCFIT_TRY(pcfit_ovality_batch_dev(dcx, dcy, dco, S, max_cand, dfit, dov, ddev.as<double>(), grid_len, st));
+    DevBuf dows;
+    if (max_cand > OV_CAP) PCFIT_TRY(dows.alloc(pcfit_ovality_workspace_bytes(n_cand, S)));
+    PCFIT_TRY(pcfit_ovality_long_dev(dcx, dcy, dco, S, n_cand, max_cand, dfit, dov, ddev.as<double>(), grid_len, dows.p,
+                                     dows.bytes, st));
 
     // (with very many candidates - all distinct points of long slices - the sections go out one by one
     // instead: a staging copy of that size would cost more than the calls it saves)

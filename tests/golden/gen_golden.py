@@ -325,6 +325,68 @@ def g_data_io():
     save("data_io", **out)
 
 
+# 12. slices beyond one workgroup's LDS: every distinct point, all-point candidates, the profile of 1.py ----
+def scratch_script_functions(names):
+    """Function objects of the reference's scratch script 1.py.  The script reads an HDF5 file from a fixed
+    Windows path while it is imported, so only the wanted function definitions are compiled, as they stand
+    in the file, into a namespace that holds what the script's own imports would give them."""
+    import ast
+    from scipy.spatial import ConvexHull
+    from scipy.spatial import QhullError
+    path = os.path.join(REF, "1.py")
+    tree = ast.parse(open(path, encoding="utf-8").read(), path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    ns = {"np": np, "ConvexHull": ConvexHull, "QhullError": QhullError}
+    # (a name defined twice in the script: the later definition wins, as it would on import)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+def g_long_slices():
+    from scipy.spatial import ConvexHull
+    from oracle.ref_np import make_slab
+    _, profile_at_z = scratch_script_functions(["_has_enough_2d_variation", "residual_profile_at_z"])
+    out = {}
+    every = 97
+    cases = [dict(n=5000, seed=71, outlier=0.02, dup=100), dict(n=50000, seed=72, outlier=0.02, dup=500),
+             dict(n=20000, seed=73, outlier=0.0, dup=0)]
+    out["cases"] = np.array([[c["n"], c["seed"], c["outlier"], c["dup"]] for c in cases])
+    out["every"] = np.array(every)
+    for i, c in enumerate(cases):
+        pts = make_slab(**c)
+        out[f"pts_sha{i}"] = np.array(sha(pts))
+        keep = (pts[:, 2] >= -0.5) & (pts[:, 2] <= 0.5)
+        uniq = np.unique(pts[keep, :2], axis=0)
+        out[f"n_unique{i}"] = np.array(len(uniq))
+        out[f"uniq_sha{i}"] = np.array(sha(uniq))
+        out[f"uniq_sub{i}"] = uniq[::every]
+        out[f"qhull{i}"] = ConvexHull(uniq).vertices.astype(np.int64)
+        res = rcf.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=600)
+        assert np.array_equal(res["fit_points_xy"], uniq)
+        out[f"fit{i}"] = np.array([res["center_x"], res["center_y"], res["radius"]])
+        out[f"mask{i}"] = res["inlier_mask"]
+        out[f"cand{i}"] = res["candidates_xy"]
+        # all distinct points as candidates (circle_fitting.py:196-198 by request)
+        res_all = rcf.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=150, use_hull_vertices_only=False)
+        assert np.array_equal(res_all["candidates_xy"], uniq)
+        out[f"all_fit{i}"] = np.array([res_all["center_x"], res_all["center_y"], res_all["radius"]])
+        out[f"all_mask_sha{i}"] = np.array(sha(res_all["inlier_mask"]))
+        out[f"all_mask_sum{i}"] = np.array(int(res_all["inlier_mask"].sum()))
+        ov = rbd.ovality_and_fourier(uniq[:, 0], uniq[:, 1], *out[f"all_fit{i}"])
+        out[f"all_ov{i}"] = np.array([ov["Rmax"], ov["Rmin"], ov["ovality_abs"], ov["ovality_pct"], ov["k2_amp"]])
+        out[f"all_dev_sub{i}"] = ov["dev_uniform"][::every]
+        # 1.py:301-345 on the same window
+        for tag, flag in (("hull", True), ("all", False)):
+            pr = profile_at_z(pts, res, 0.0, 0.5, use_hull_vertices=flag)
+            sub = slice(None) if flag else slice(None, None, every)
+            out[f"prof_{tag}_n{i}"] = np.array(len(pr["theta"]))
+            out[f"prof_{tag}_theta{i}"] = pr["theta"][sub]
+            out[f"prof_{tag}_dr{i}"] = pr["delta_r"][sub]
+            out[f"prof_{tag}_xy{i}"] = pr["xy_used"][sub]
+            out[f"prof_{tag}_xy_sha{i}"] = np.array(sha(pr["xy_used"]))
+    save("long_slices", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[2:]
     if only:
@@ -339,3 +401,4 @@ if __name__ == "__main__":
     g_hull_hybrid()
     g_boundary()
     g_analyzer()
+    g_long_slices()

@@ -593,9 +593,9 @@ def test_full_size_ransac_30pct_outliers():
 
 # ------------------------------------------------------------------ long slices, scan-sized inputs
 def test_unique_hull_on_slices_longer_than_lds():
-    """Slices of 20 000 and 70 000 points first lose the points that are provably inside the hull (sector filter),
-    then run the sort / hull kernel on what is left: same hull vertices in the same order; the unique points
-    reported for such a slice are the kept ones, a sorted subset of all unique points."""
+    """Slices of 20 000 and 70 000 points: every distinct point comes back, sorted (tile sort + rank merges through
+    global memory), and the hull - found on what the sector filter leaves - indexes that full set: same vertices in
+    the same order as the CPU hull.  The hybrid call without ux / uy reports the filter's survivors in n_unique."""
     gen = np.random.default_rng(11)
     sets = []
     # (points, outlier share, arc): outliers pull the centroid off the centre; a lopsided density does so
@@ -615,22 +615,25 @@ def test_unique_hull_on_slices_longer_than_lds():
         sets.append(xy)
     x, y, off = csr(sets)
     h = F.unique_hull_batch(x, y, off)
+    starts = np.full(len(sets), -1, np.int64)
     for s, xy in enumerate(sets):
         uniq = R.unique_rows(xy)
         o = off[s]
         nu, nh = int(h["n_unique"][s]), int(h["n_hull"][s])
-        kept = np.stack([h["ux"][o:o + nu], h["uy"][o:o + nu]], 1)
-        if len(xy) <= 8192:
-            assert nu == len(uniq) and np.array_equal(kept, uniq)
-            assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
-        elif len(xy) == 12_000:
-            assert nu == len(uniq)                                            # open arc: empty sectors, all kept
-            assert np.array_equal(kept[h["hull_idx"][o:o + nh]], uniq[N.hull(uniq)]), s
-        else:
-            assert 3 <= nu < 0.3 * len(uniq)                                  # the filter did its job
-            assert np.array_equal(kept, R.unique_rows(kept))                  # sorted, no duplicates
-            assert set(map(tuple, kept)) <= set(map(tuple, uniq))
-            assert np.array_equal(kept[h["hull_idx"][o:o + nh]], uniq[N.hull(uniq)]), s
+        assert nu == len(uniq) and np.array_equal(np.stack([h["ux"][o:o + nu], h["uy"][o:o + nu]], 1), uniq), s
+        assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
+        starts[s] = h["hull_idx"][o + nh // 3]
+    # a requested first vertex is honoured on long slices as well
+    starts[2] = -1
+    h2 = F.unique_hull_batch(x, y, off, hull_start=starts)
+    for s in range(len(sets)):
+        o, nh = off[s], int(h["n_hull"][s])
+        want = h["hull_idx"][o:o + nh]
+        k = 0 if starts[s] < 0 else nh // 3
+        assert np.array_equal(h2["hull_idx"][o:o + nh], np.concatenate([want[k:], want[:k]])), s
+    lean = F.hybrid_batch(x, y, off, max_trials=50, want_unique=False, want_profile=False)
+    full = np.array([len(R.unique_rows(xy)) for xy in sets])
+    assert np.all(lean["n_unique"] <= full) and lean["n_unique"][1] < 0.3 * full[1] and lean["n_unique"][5] == full[5]
     hy = F.hybrid_batch(x, y, off, max_trials=300)
     assert np.all(hy["status"] == 0)
     for s, xy in enumerate(sets):
@@ -643,8 +646,8 @@ def test_unique_hull_on_slices_longer_than_lds():
 
 def test_many_long_slices_take_the_narrow_hull_launch():
     """From 512 slices on, what the sector filter leaves of a long slice goes to a launch of 256-thread workgroups
-    when it is short: the same kept points, hull vertices and order as the 1024-thread launch that smaller batches
-    use, and as the CPU hull on sampled slices. One slice keeps more than the narrow launch holds (an open arc is
+    when it is short: the same distinct points, hull vertices and order as the 1024-thread launch that smaller
+    batches use, and as the CPU hull on sampled slices. One slice keeps more than the narrow launch holds (an open arc is
     not filtered), two are shorter than the LDS and never filtered."""
     gen = np.random.default_rng(77)
     sets = []
@@ -673,13 +676,86 @@ def test_many_long_slices_take_the_narrow_hull_launch():
             assert np.array_equal(h["uy"][o:o + nu], g["uy"][og:og + nu]), s
             assert np.array_equal(h["hull_idx"][o:o + nh], g["hull_idx"][og:og + nh]), s
     assert h["n_unique"][100] == len(R.unique_rows(sets[100])) > 2048
-    assert np.median(h["n_unique"]) < 2048
+    lean = F.hybrid_batch(x, y, off, max_trials=20, want_unique=False, want_profile=False)
+    assert np.median(lean["n_unique"]) < 2048                   # what the filter left is what the narrow launch took
     for s in (0, 7, 100, 300, 519):
         uniq = R.unique_rows(sets[s])
         o = off[s]
         nu, nh = int(h["n_unique"][s]), int(h["n_hull"][s])
         kept = np.stack([h["ux"][o:o + nu], h["uy"][o:o + nu]], 1)
         assert np.array_equal(kept[h["hull_idx"][o:o + nh]], uniq[N.hull(uniq)]), s
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_long_slices_against_the_reference_run():
+    """Windows of 5 000, 50 000 and 20 000 points through the drop-in functions, against what the reference
+    returned for them (tests/golden/long_slices.npz): fit_points_xy = every distinct point; hull candidates in
+    Qhull's order (first vertex handed over), inlier mask and fit; all distinct points as candidates
+    (use_hull_vertices_only=False); ovality over that many candidates; residual_profile_at_z (1.py:301-345) over
+    hull vertices and over all points."""
+    from pointcloud_amd.utils import boundary as B
+    from pointcloud_amd.utils import circle_fitting as CF
+    from pointcloud_amd.utils import residuals as RS
+    g = load_golden("long_slices")
+    every = int(g["every"])
+    for i, (n, seed, outlier, dup) in enumerate(g["cases"]):
+        pts = R.make_slab(int(n), int(seed), float(outlier), int(dup))
+        assert _sha(pts) == str(g[f"pts_sha{i}"])
+        q = g[f"qhull{i}"]
+        res = CF.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=600, hull_start=int(q[0]))
+        assert len(res["fit_points_xy"]) == int(g[f"n_unique{i}"]) and _sha(res["fit_points_xy"]) == str(g[f"uniq_sha{i}"])
+        assert np.array_equal(res["candidates_xy"], g[f"cand{i}"])
+        assert np.array_equal(res["inlier_mask"], g[f"mask{i}"])
+        assert rel([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"]) < 1e-9
+        allc = CF.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=150, use_hull_vertices_only=False)
+        assert _sha(allc["candidates_xy"]) == str(g[f"uniq_sha{i}"])
+        assert int(allc["inlier_mask"].sum()) == int(g[f"all_mask_sum{i}"])
+        assert _sha(allc["inlier_mask"]) == str(g[f"all_mask_sha{i}"])
+        assert rel([allc["center_x"], allc["center_y"], allc["radius"]], g[f"all_fit{i}"]) < 1e-9
+        uniq = res["fit_points_xy"]
+        ov = B.ovality_and_fourier(uniq[:, 0], uniq[:, 1], *g[f"all_fit{i}"])
+        got = [ov[k] for k in ("Rmax", "Rmin", "ovality_abs", "ovality_pct", "k2_amp")]
+        assert rel(got[:2], g[f"all_ov{i}"][:2]) < 4e-16 and rel(got[2:], g[f"all_ov{i}"][2:]) < 1e-9
+        assert np.max(np.abs(ov["dev_uniform"][::every] - g[f"all_dev_sub{i}"])) < 1e-12
+        fit = dict(center_x=g[f"fit{i}"][0], center_y=g[f"fit{i}"][1], radius=g[f"fit{i}"][2])
+        for tag, flag, sub in (("hull", True, slice(None)), ("all", False, slice(None, None, every))):
+            pr = RS.residual_profile_at_z(pts, fit, 0.0, 0.5, use_hull_vertices=flag)
+            assert len(pr["theta"]) == int(g[f"prof_{tag}_n{i}"])
+            assert _sha(pr["xy_used"]) == str(g[f"prof_{tag}_xy_sha{i}"]), (i, tag)
+            assert np.max(np.abs(pr["theta"][sub] - g[f"prof_{tag}_theta{i}"])) <= THETA_ABS
+            assert np.max(np.abs(pr["delta_r"][sub] - g[f"prof_{tag}_dr{i}"])) <= 4e-15
+            # ... and every value, not only the recorded sample, against the CPU restatement
+            ref = R.residual_profile_at_z(pts, fit, 0.0, 0.5, use_hull_vertices=flag)
+            assert np.array_equal(pr["xy_used"], ref["xy_used"])
+            assert np.max(np.abs(pr["theta"] - ref["theta"])) <= THETA_ABS
+            assert np.max(np.abs(pr["delta_r"] - ref["delta_r"])) <= 4e-15
+
+
+def test_distinct_points_of_a_million_point_slice_and_of_many_long_slices():
+    """np.unique(axis=0) of one slice of 1.2 M points (8 merge passes) and of 300 slices of 9 000 to 40 000 points
+    with many duplicates, bit for bit; hull indices point into the full sorted set."""
+    gen = np.random.default_rng(5)
+    big = R.make_slab(1_200_000, 81, outlier=0.05, dup=100_000)[:, :2]
+    sets = [big]
+    for s in range(300):
+        n = int(gen.integers(9_000, 40_000))
+        xy = R.make_slab(n, 1000 + s, outlier=0.02)[:, :2]
+        xy = np.round(xy, 2) if s % 3 == 0 else xy            # a coarse grid: most points repeat
+        sets.append(xy)
+    sets.append(np.repeat(np.array([[1.0, 2.0]]), 10_000, axis=0))      # one point 10 000 times
+    x, y, off = csr(sets)
+    h = F.unique_hull_batch(x, y, off)
+    for s, xy in enumerate(sets):
+        uniq = R.unique_rows(xy)
+        o, nu, nh = off[s], int(h["n_unique"][s]), int(h["n_hull"][s])
+        assert nu == len(uniq), s
+        assert np.array_equal(h["ux"][o:o + nu], uniq[:, 0]) and np.array_equal(h["uy"][o:o + nu], uniq[:, 1]), s
+        if s in (0, 1, 2, 3, 150, 300):
+            assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
+    assert h["status"][-1] == 1 and h["n_unique"][-1] == 1
 
 
 def test_one_million_point_scan_through_the_analyzer():

@@ -98,6 +98,45 @@ def test_unique_hull_hybrid():
         assert close([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"], 1e-9)
 
 
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_long_slices_every_distinct_point_and_the_profile_of_the_scratch_script():
+    """Windows of 5 000 to 50 000 points: np.unique of the whole window, hull candidates in Qhull's order, all
+    distinct points as candidates, ovality over 50 000 candidates, and residual_profile_at_z (1.py:301-345)
+    over hull vertices and over all points - against what the reference returned."""
+    g = load_golden("long_slices")
+    every = int(g["every"])
+    for i, (n, seed, outlier, dup) in enumerate(g["cases"]):
+        pts = R.make_slab(int(n), int(seed), float(outlier), int(dup))
+        assert _sha(pts) == str(g[f"pts_sha{i}"])
+        keep = (pts[:, 2] >= -0.5) & (pts[:, 2] <= 0.5)
+        uniq = R.unique_rows(pts[keep, :2])
+        assert len(uniq) == int(g[f"n_unique{i}"]) and _sha(uniq) == str(g[f"uniq_sha{i}"])
+        q = g[f"qhull{i}"]
+        res = R.hybrid_fit(pts, 0.0, 0.5, max_trials=600, hull_start=int(q[0]))
+        assert np.array_equal(res["candidates_xy"], g[f"cand{i}"])
+        assert np.array_equal(res["inlier_mask"], g[f"mask{i}"])
+        assert close([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"], 1e-9)
+        assert np.array_equal(res["fit_points_xy"], uniq)
+        allc = R.hybrid_fit(pts, 0.0, 0.5, max_trials=150, use_hull_vertices_only=False)
+        assert np.array_equal(allc["candidates_xy"], uniq)
+        assert _sha(allc["inlier_mask"]) == str(g[f"all_mask_sha{i}"])
+        assert close([allc["center_x"], allc["center_y"], allc["radius"]], g[f"all_fit{i}"], 1e-9)
+        ov = R.ovality_fourier(uniq[:, 0], uniq[:, 1], *g[f"all_fit{i}"])
+        assert close([ov[k] for k in ("Rmax", "Rmin", "ovality_abs", "ovality_pct", "k2_amp")], g[f"all_ov{i}"], 1e-12)
+        assert close(ov["dev_uniform"][::every], g[f"all_dev_sub{i}"], 1e-12)
+        fit = dict(center_x=g[f"fit{i}"][0], center_y=g[f"fit{i}"][1], radius=g[f"fit{i}"][2])
+        for tag, flag, sub in (("hull", True, slice(None)), ("all", False, slice(None, None, every))):
+            pr = R.residual_profile_at_z(pts, fit, 0.0, 0.5, use_hull_vertices=flag, hull_start=int(q[0]))
+            assert len(pr["theta"]) == int(g[f"prof_{tag}_n{i}"])
+            assert _sha(pr["xy_used"]) == str(g[f"prof_{tag}_xy_sha{i}"])
+            assert np.array_equal(pr["xy_used"][sub], g[f"prof_{tag}_xy{i}"])
+            assert np.all(ulp_diff(pr["theta"][sub], g[f"prof_{tag}_theta{i}"]) <= 4)
+            assert np.all(np.abs(pr["delta_r"][sub] - g[f"prof_{tag}_dr{i}"]) <= 4e-15)
+
+
 def _ring(n, seed, r=10.0, c=(3.0, -2.0), sigma=0.05):
     gen = np.random.default_rng(seed)
     th = gen.uniform(0, 2 * np.pi, n)
