@@ -53,34 +53,121 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def cpu_baseline(x, y, off, bins, lo, hi, budget_s=14.0, max_slices=2000):
-    """numpy restatement of the same step (Kasa -> LM -> residual histogram), slice after slice,
-    on the host: the stand-in for the reference's CPU path, which cannot travel."""
+def _cpu_step_np(x, y, off, s, bins, lo, hi):
+    """The step for slice s as the numpy restatement of the reference evaluates it (Kasa -> LM -> residuals)."""
     from oracle import ref_np as R
+    sl = slice(off[s], off[s + 1])
+    xs, ys = x[sl], y[sl]
+    k = R.kasa_fit(xs, ys)
+    f = R.lm_huber(xs, ys, *k)
+    theta, r = R.polar(np.stack([xs, ys], 1), f[0], f[1])
+    R.residual_histogram(r - f[2], bins, lo, hi)
+    int(np.argmax(r)), int(np.argmin(r))
+    return xs.size
+
+
+def cpu_baseline(x, y, off, bins, lo, hi, budget_s=10.0, max_slices=2000):
+    """numpy restatement of the same step, slice after slice, on one host thread: the stand-in for the
+    reference's serial loop (analyzer.py:148), which cannot travel."""
     t0 = time.perf_counter()
     done = pts = 0
     while done < max_slices and time.perf_counter() - t0 < budget_s:
-        sl = slice(off[done], off[done + 1])
-        xs, ys = x[sl], y[sl]
-        k = R.kasa_fit(xs, ys)
-        f = R.lm_huber(xs, ys, *k)
-        theta, r = R.polar(np.stack([xs, ys], 1), f[0], f[1])
-        R.residual_histogram(r - f[2], bins, lo, hi)
-        int(np.argmax(r)), int(np.argmin(r))
+        pts += _cpu_step_np(x, y, off, done, bins, lo, hi)
         done += 1
-        pts += xs.size
     dt = time.perf_counter() - t0
     return pts / dt, done, dt
 
 
-def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600):
+def cpu_baseline_pool(x, y, off, bins, lo, hi, threads, n_slices):
+    """The same slices through ThreadPoolExecutor(threads), the reference's own parallel driver
+    (analyzer.py:203-207: one task per slice)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n_slices = min(n_slices, len(off) - 1)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        pts = sum(pool.map(lambda s: _cpu_step_np(x, y, off, s, bins, lo, hi), range(n_slices)))
+    dt = time.perf_counter() - t0
+    return pts / dt, n_slices, dt
+
+
+def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600, threads=1):
+    """Plain C restatement (literal 100-iteration LM loop, no interpreter in the way), on `threads` host
+    threads (ctypes releases the GIL during the call), each taking a contiguous share of the slices."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import native as N
     n_slices = min(n_slices, len(off) - 1)
-    end = off[n_slices]
+    cuts = np.linspace(0, n_slices, threads + 1).astype(int)
+
+    def share(t):
+        a, b = cuts[t], cuts[t + 1]
+        if b > a:
+            N.fit_residual_batch(x[off[a]:off[b]], y[off[a]:off[b]], off[a:b + 1] - off[a], bins, lo, hi)
+
+    N.lib()
     t0 = time.perf_counter()
-    N.fit_residual_batch(x[:end], y[:end], off[:n_slices + 1], bins, lo, hi)
+    if threads == 1:
+        share(0)
+    else:
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(share, range(threads)))
     dt = time.perf_counter() - t0
-    return end / dt, n_slices, dt
+    return off[n_slices] / dt, n_slices, dt
+
+
+def extra_configs(L, dev, stream):
+    """Timings of the other configurations, outside the timed region (events on the kernels' stream):
+    seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice."""
+    out = {}
+
+    def timed(fn, reps):
+        fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    S, n, T = 10_000, 8192, 1024
+    g = torch.Generator(device=dev)
+    g.manual_seed(2)
+    ang = torch.rand(S * n, generator=g, device=dev, dtype=torch.float64) * (2 * np.pi)
+    r = 10.0 + 0.05 * torch.randn(S * n, generator=g, device=dev, dtype=torch.float64)
+    bad = torch.rand(S * n, generator=g, device=dev, dtype=torch.float64) < 0.3
+    r = torch.where(bad, torch.rand(S * n, generator=g, device=dev, dtype=torch.float64) * 14.0, r)
+    x, y = 3.0 + r * torch.cos(ang), -2.0 + r * torch.sin(ang)
+    del ang, r, bad
+    off = torch.arange(S + 1, device=dev, dtype=torch.int64) * n
+    tab = torch.from_numpy(F.choice3_table(n, T)).to(dev)
+    tof = torch.zeros(S, dtype=torch.int32, device=dev)
+    model = torch.empty(S, 3, dtype=torch.float64, device=dev)
+    score, best, st = (torch.empty(S, dtype=torch.int32, device=dev) for _ in range(3))
+    mask = torch.empty(S * n, dtype=torch.uint8, device=dev)
+    ws = torch.empty(L.pcfit_ransac_workspace_bytes(S), dtype=torch.uint8, device=dev)
+    ms = timed(lambda: F.check(L.pcfit_ransac_batch_dev(ptr(x), ptr(y), ptr(off), S, 0.5, T, 0.1, None, ptr(tab),
+                                                        ptr(tof), ptr(model), ptr(score), ptr(best), ptr(mask), ptr(st),
+                                                        ptr(ws), ws.numel(), stream)), 2)
+    evals = float(S) * n * T
+    out["ransac_10000x8192_1024_hypotheses_30pct_outliers"] = {
+        "ms": ms, "points_per_s": S * n / (ms * 1e-3), "point_hypotheses_per_s": evals / (ms * 1e-3),
+        "tflops_at_7_flop": evals * 7 / (ms * 1e-3) / 1e12,
+        "valu_fp64_frac": evals * 7 / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
+        "min_score": int(score.min().item()), "all_ok": bool((st == 0).all().item())}
+    return out
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` started plainly: run the N ranks as a child `torch.distributed.run` (this process has
+    not touched the GPU yet and never will) and pass rank 0's line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd)
 
 
 def main():
@@ -92,11 +179,17 @@ def main():
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the timings of the other configurations")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL) on GPUs; gloo only rehearses the launch")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # (more ranks than GPUs only happens in a rehearsal of the launch on a smaller box, with --backend gloo)
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # The fit kernels run on a stream of their own at normal priority and the process group's stream is asked for
@@ -112,9 +205,12 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
-        opts = dist.ProcessGroupNCCL.Options()
-        opts.is_high_priority_stream = True
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        if a.backend == "nccl":
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world, pg_options=opts)
+        else:
+            dist.init_process_group(a.backend, rank=rank, world_size=world)
     L = F.lib()
 
     S, n, H = a.slices, a.points, a.bins
@@ -141,8 +237,10 @@ def main():
     status = torch.empty(S, dtype=torch.int32, device=dev)
     rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
     amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
+    on_host = use_dist and a.backend != "nccl"          # rehearsal: the exchange goes through host memory
     if use_dist:
-        gathered = [torch.empty(world * rec_bytes, dtype=torch.uint8, device=dev) for _ in range(RING)]
+        gathered = [torch.empty(world * rec_bytes, dtype=torch.uint8, device="cpu" if on_host else dev)
+                    for _ in range(RING)]
     pending = [None] * RING
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     ev_k = []
@@ -168,7 +266,10 @@ def main():
         if use_dist:
             hist_wire[b].copy_(hist)
             # (bytes on the wire: RCCL has no 16-bit integer type)
-            pending[b] = dist.all_gather_into_tensor(gathered[b], record[b], async_op=True)
+            if on_host:
+                dist.all_gather_into_tensor(gathered[b], record[b].cpu())
+            else:
+                pending[b] = dist.all_gather_into_tensor(gathered[b], record[b], async_op=True)
 
     def drain():
         for b in range(RING):
@@ -196,9 +297,11 @@ def main():
     if os.environ.get("PCFIT_BENCH_DEBUG") == "1":
         print(f"[bench] host enqueue {t_host / a.steps * 1e3:.3f} ms/step of {dt / a.steps * 1e3:.3f}", file=sys.stderr)
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if on_host else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # sweeps of the timed launches, read before anything else writes `iters`
+    it = iters.cpu().numpy().astype(np.float64)
 
     # the subsystems on their own, after the timed region: algebraic fit, fit without residuals, residuals
     def timed(fn, reps=5):
@@ -214,18 +317,21 @@ def main():
 
     side = []
     if rank == 0:
+        iters_side = torch.empty_like(iters)
+        fit_side = torch.empty(S, 3, dtype=torch.float64, device=dev)
+        fit_side.copy_(fit[(a.warmup + a.steps - 1) % RING] if a.steps + a.warmup > 0 else fit[0])
         for name, fn in (
             ("kasa_kernel (algebraic fit)", lambda: F.check(L.pcfit_kasa_batch_dev(
                 ptr(x), ptr(y), ptr(off), S, n, ptr(kasa), ptr(status), stream))),
             ("fit_kernel (Kasa + LM)", lambda: F.check(L.pcfit_fit_batch_dev(
-                ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit[0]), ptr(iters),
+                ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit_side), ptr(iters_side),
                 ptr(status), stream))),
             ("fit_residual_kernel with max_iter = 0 (Kasa + residual pass, one read of the slice)",
              lambda: F.check(L.pcfit_fit_residuals_batch_dev(
-                 ptr(x), ptr(y), ptr(off), S, n, 1.0, 0, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit[0]), ptr(iters),
+                 ptr(x), ptr(y), ptr(off), S, n, 1.0, 0, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit_side), ptr(iters_side),
                  ptr(status), H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream))),
             ("residuals_kernel (histogram + extremes)", lambda: F.check(L.pcfit_residuals_batch_dev(
-                ptr(x), ptr(y), ptr(off), S, ptr(fit[0]), None, None, None, H, ptr(edges), ptr(hist), ptr(rmm),
+                ptr(x), ptr(y), ptr(off), S, ptr(fit_side), None, None, None, H, ptr(edges), ptr(hist), ptr(rmm),
                 ptr(amm), stream))),
         ):
             ms = timed(fn)
@@ -234,7 +340,6 @@ def main():
 
     ms_step = dt / a.steps * 1e3
     k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_k]))
-    it = iters.cpu().numpy().astype(np.float64)
     sweeps = it[:, 2] + it[:, 3]
     flop_launch = float(n * (FLOP_SWEEP * sweeps.sum() + (FLOP_KASA + FLOP_RESID) * S))
     alg_bytes = float(S * n * 16)
@@ -261,7 +366,9 @@ def main():
             "config": {"workload": f"{S} slices x {n} points per GPU, Kasa+LM/Huber fit then residual "
                                    f"histogram ({H} bins) + Rmax/Rmin, pre-binned CSR, noisy cylinder sigma=0.05",
                        "slices_per_gpu": S, "points_per_slice": n, "hist_bins": H,
-                       "parallelism": f"slice-sharded x{world}" + (", RCCL all-gather of fits+histograms" if world > 1 else "")},
+                       "parallelism": f"slice-sharded x{world}" + ((", RCCL all-gather of fits+histograms" if a.backend == "nccl" else
+                                                                         f", {a.backend} all-gather through host memory (launch rehearsal)")
+                                                                        if world > 1 else "")},
             # The metric asks for the fraction of the HBM roofline; the pass itself is bound by FP64 vector
             # issue (see roofline_valu), so this fraction cannot approach 1: three LM sweeps, the Kasa
             # moments and a correctly rounded hypot per point are ~220 vector instructions per 16 bytes.
@@ -284,15 +391,39 @@ def main():
             },
             "kernels": side,
         }
+        # the pass the 50 %-of-HBM target is stated for: algebraic fit + residual statistics, one read of the slice
+        kr = side[2]
+        out["roofline_kasa_residual_pass"] = {
+            "kernel": "fit_residual_kernel<16,16,256> with max_iter = 0", "bound": "hbm", "achieved": kr["hbm_gbs"],
+            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kr["hbm_frac"], "avg_launch_ms": kr["ms"],
+            "algorithmic_bytes": alg_bytes}
+        if not a.no_extra:
+            out["extra"] = extra_configs(L, dev, stream)
         if world == 1 and not a.no_cpu_baseline:
+            host_cpus = os.cpu_count() or 1
+            # (on a shared box os.cpu_count() is the whole machine; a job's share is what OMP_NUM_THREADS says)
+            threads = max(1, min(host_cpus, int(os.environ.get("OMP_NUM_THREADS", "16") or 16), 64))
             rate, k, secs = cpu_baseline(xh, yh, offh, H, lo, hi)
             out["cpu_baseline"] = {"value": rate, "unit": "points/s", "cores": 1, "kind": "port",
+                                   "host_cpu_count": host_cpus,
                                    "sample": f"numpy restatement of the same step on the first {k} slices "
-                                             f"({k * n} points, {secs:.1f} s, one Python thread)"}
+                                             f"({k * n} points, {secs:.1f} s, one Python thread, the reference's "
+                                             f"serial loop analyzer.py:148)"}
+            rate_p, kp, secs_p = cpu_baseline_pool(xh, yh, offh, H, lo, hi, threads, max(4 * threads, k // 2))
+            out["cpu_baseline_pool"] = {"value": rate_p, "unit": "points/s", "cores": threads, "kind": "port",
+                                        "host_cpu_count": host_cpus,
+                                        "sample": f"the same through ThreadPoolExecutor({threads}) as analyzer.py:203-207 "
+                                                  f"on {kp} slices, {secs_p:.1f} s"}
             rate_c, kc, secs_c = cpu_baseline_c(xh, yh, offh, H, lo, hi)
             out["cpu_baseline_c"] = {"value": rate_c, "unit": "points/s", "cores": 1, "kind": "port",
-                                     "sample": f"plain C restatement (literal 100 iterations) on {kc} slices, {secs_c:.1f} s"}
+                                     "sample": f"plain C restatement (literal 100 iterations, no interpreter) on {kc} "
+                                               f"slices, {secs_c:.1f} s"}
+            rate_ct, kct, secs_ct = cpu_baseline_c(xh, yh, offh, H, lo, hi, n_slices=600 * threads, threads=threads)
+            out["cpu_baseline_c_threads"] = {"value": rate_ct, "unit": "points/s", "cores": threads, "kind": "port",
+                                             "sample": f"the C restatement on {threads} host threads, {kct} slices, "
+                                                       f"{secs_ct:.1f} s"}
             out["gpu_over_cpu"] = out["value"] / rate
+            out["gpu_over_best_cpu"] = out["value"] / max(rate, rate_p, rate_c, rate_ct)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
