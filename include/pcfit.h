@@ -53,7 +53,11 @@ extern "C" {
 int pcfit_version(void);
 const char *pcfit_last_error(void);
 int pcfit_device_count(int *count);
+/* The current device is a property of the calling THREAD (as in HIP): a new
+ * thread starts on device 0 whatever its parent selected.  A scan handle
+ * (pcfit_scan_upload) belongs to the device current in the thread that made it. */
 int pcfit_set_device(int device);
+int pcfit_get_device(int *device);
 int pcfit_malloc(void **ptr, size_t bytes);
 int pcfit_free(void *ptr);
 int pcfit_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, void *stream);
@@ -385,6 +389,22 @@ int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const
                                double *cand_x, double *cand_y, uint8_t *mask, double *radius, double *theta,
                                int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
                                int64_t cand_capacity);
+
+/* ---- one scan over several GPUs: what a rank needs of it (host cores + one upload) ---- */
+/* A rank that analyses the windows [z_lo[a], z_hi[b]] of a scan needs only the rows with
+ * z inside that range (analyzer.py:49-52 reads nothing else for those windows).  These
+ * three calls let every rank find its windows and upload its rows without a pass of the
+ * interpreter over the scan: numpy's points[:,2].min() / .max() (analyzer.py:236; both NaN
+ * if any z is NaN), the window populations n0 of analyzer.py:49-54 for all windows (same
+ * closed-interval rule as the device binning), and pcfit_scan_upload restricted to the rows
+ * with z_lo <= z <= z_hi, which keep their file order (so every window of the range holds
+ * the same points in the same order as in the whole scan).  n_threads: 0 = one per core,
+ * at most 16. */
+int pcfit_host_z_range(const double *xyz, int64_t n_points, int32_t n_threads, double *z_min_max);
+int pcfit_host_window_counts(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                             int64_t n_slices, int32_t n_threads, int64_t *counts);
+int pcfit_scan_upload_z_range(const double *xyz, int64_t n_points, double z_lo, double z_hi, pcfit_scan **scan,
+                              int64_t *n_kept);
 
 /* ---- the step after the path: CSV rows (host cores only) -------------------- */
 /* The body of slice_points.csv as save_results writes it (utils/data_io.py:43-46:

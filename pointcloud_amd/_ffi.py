@@ -36,6 +36,7 @@ SIGNATURES = {
     "pcfit_last_error": (C.c_char_p, []),
     "pcfit_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "pcfit_set_device": (C.c_int, [C.c_int]),
+    "pcfit_get_device": (C.c_int, [C.POINTER(C.c_int)]),
     "pcfit_malloc": (C.c_int, [C.POINTER(_vp), _sz]),
     "pcfit_free": (C.c_int, [_vp]),
     "pcfit_memcpy_h2d": (C.c_int, [_vp, _vp, _sz, _vp]),
@@ -93,6 +94,9 @@ SIGNATURES = {
     "pcfit_parse_xyz_text": (C.c_int, [_vp, _sz, _i32, _vp, _vp, _i64, _vp]),
     "pcfit_scan_upload": (C.c_int, [_vp, _i64, C.POINTER(_vp), _vp]),
     "pcfit_scan_free": (C.c_int, [_vp]),
+    "pcfit_host_z_range": (C.c_int, [_vp, _i64, _i32, _vp]),
+    "pcfit_host_window_counts": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i32, _vp]),
+    "pcfit_scan_upload_z_range": (C.c_int, [_vp, _i64, _f64, _f64, C.POINTER(_vp), _vp]),
     "pcfit_scan_bin_slices": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pcfit_scan_window_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
@@ -122,6 +126,17 @@ def lib():
 def check(rc: int):
     if rc != 0:
         raise PcfitError(f"pcfit error {rc}: {lib().pcfit_last_error().decode(errors='replace')}")
+
+
+def current_device() -> int:
+    """The HIP device of the calling thread (a new thread starts on device 0)."""
+    d = C.c_int(0)
+    check(lib().pcfit_get_device(C.byref(d)))
+    return d.value
+
+
+def set_device(device: int):
+    check(lib().pcfit_set_device(int(device)))
 
 
 def _arr(a, dtype):
@@ -338,12 +353,22 @@ class DeviceScan:
     """A scan uploaded once and kept on the GPU (pcfit_scan_upload): ``n_points``, and ``z_min`` / ``z_max``
     as numpy's ``points[:, 2].min()`` / ``.max()``.  Free it with ``close()`` (or let it go out of scope)."""
 
-    def __init__(self, points):
+    def __init__(self, points, z_range=None):
+        """``z_range`` = (lo, hi): only the rows with lo <= z <= hi go to the GPU (in their order);
+        z_min / z_max are then not computed (NaN)."""
         pts = _arr(points, np.float64)
         if pts.ndim != 2 or pts.shape[1] != 3:
             raise ValueError("points must be (N,3)")
-        self.n_points = int(pts.shape[0])
+        self.device = current_device()         # the handle belongs to this device
         self._handle = _vp()
+        if z_range is not None:
+            kept = C.c_int64(0)
+            check(lib().pcfit_scan_upload_z_range(_p(pts), int(pts.shape[0]), float(z_range[0]), float(z_range[1]),
+                                                  C.byref(self._handle), C.addressof(kept)))
+            self.n_points = int(kept.value)
+            self.z_min = self.z_max = float("nan")
+            return
+        self.n_points = int(pts.shape[0])
         zr = np.full(2, np.nan)
         check(lib().pcfit_scan_upload(_p(pts), self.n_points, C.byref(self._handle), _p(zr)))
         self.z_min, self.z_max = float(zr[0]), float(zr[1])
@@ -374,6 +399,26 @@ class DeviceScan:
         if z_lo.size:
             check(lib().pcfit_scan_window_counts(self._handle, _p(z_lo), _p(z_hi), z_lo.size, _p(counts)))
         return counts
+
+
+def host_z_range(points, n_threads: int = 0):
+    """numpy's points[:, 2].min(), .max() by the library's host threads (both NaN if any z is NaN)."""
+    pts = _arr(points, np.float64)
+    zr = np.full(2, np.nan)
+    check(lib().pcfit_host_z_range(_p(pts), int(pts.shape[0]), n_threads, _p(zr)))
+    return float(zr[0]), float(zr[1])
+
+
+def host_window_counts(points, z_lo, z_hi, n_threads: int = 0):
+    """Points per closed window [z_lo[s], z_hi[s]], counted on the host (several threads)."""
+    pts = _arr(points, np.float64)
+    z_lo = _arr(z_lo, np.float64)
+    z_hi = _arr(z_hi, np.float64)
+    counts = np.zeros(z_lo.size, np.int64)
+    if z_lo.size:
+        check(lib().pcfit_host_window_counts(_p(pts), int(pts.shape[0]), _p(z_lo), _p(z_hi), z_lo.size, n_threads,
+                                             _p(counts)))
+    return counts
 
 
 def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,

@@ -48,18 +48,6 @@ class CylinderAnalyzer:
         self.points_csv = 'slice_points.csv'
         self.overlay_png = 'all_circles_overlay.png'
 
-    # ------------------------------------------------------------------ batch core
-    def _run_windows(self, points: np.ndarray, z_centers: np.ndarray, hull_start=None, want_profile=True):
-        """Bin ``points`` into the closed windows around ``z_centers`` and run the
-        hybrid fit on every window.  Returns (offsets, x, y, hybrid-dict)."""
-        dz = self.config.z_step / 2.0
-        z_centers = np.asarray(z_centers, float)
-        offsets, x, y, _ = _ffi.bin_slices(points, z_centers - dz, z_centers + dz, want_perm=False)
-        h = _ffi.hybrid_batch(x, y, offsets, _FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None,
-                              _FIT["huber_delta"], _FIT["use_hull"], hull_start, want_profile=want_profile,
-                              want_unique=False)
-        return offsets, x, y, h
-
     def _slice_result(self, s: int, z_center, n0: int, h: dict, want_ov: bool = True):
         """Result dict, edge frame columns and the ovality dict of slice ``s``
         (reference: analyzer.py:77-127).  ``want_ov=False`` leaves out the two
@@ -116,10 +104,14 @@ class CylinderAnalyzer:
         if not isinstance(points, _ffi.DeviceScan):
             points = np.asarray(points, float)
         hs = None if hull_start is None else np.array([hull_start], np.int64)
-        offsets, x, y, h = self._run_windows(points, np.array([z_center], float), hs)
+        dz = self.config.z_step / 2.0
+        offsets, x, y, _ = _ffi.bin_slices(points, np.array([z_center - dz]), np.array([z_center + dz]),
+                                           want_perm=False)
         n0 = int(offsets[1])
         if n0 < self.config.min_points_per_slice:
             return None, None, f"SKIP zc={z_center:.3f}: too sparse ({n0} points)"
+        h = _ffi.hybrid_batch(x, y, offsets, _FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None,
+                              _FIT["huber_delta"], _FIT["use_hull"], hs, want_profile=True, want_unique=False)
         slc = np.stack([x, y], axis=1)
         if n0 > self.config.max_points_for_speed:
             # the reference thins only what it hands back for plotting; the fit sees every point

@@ -6,8 +6,11 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 
@@ -350,6 +353,107 @@ int download_staged(void *dst, const void *src, size_t bytes)
     return PCFIT_OK;
 }
 
+// ---- the part of a scan that one GPU of several needs ----
+// Host passes over the z column of a scan in pageable memory, on several threads (a slice of the rows each).
+namespace {
+int host_threads(int32_t asked)
+{
+    if (asked > 0)
+        return std::min<int32_t>(asked, 64);
+    return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+template <class F>
+void host_parallel(int T, F &&f)
+{
+    std::vector<std::thread> pool;
+    for (int t = 1; t < T; t++)
+        pool.emplace_back(f, t);
+    f(0);
+    for (auto &th : pool)
+        th.join();
+}
+}  // namespace
+
+// Rows lo <= z <= hi of xyz (n rows), in file order, to a fresh device block: counted per chunk first (so that
+// every chunk knows where its rows go), then packed chunk by chunk into the pinned staging buffers and sent.
+int upload_rows_in_z_range(const double *xyz, int64_t n, double lo, double hi, DevBuf &out, int64_t *kept)
+{
+    constexpr int64_t ROWS = (int64_t)(STAGE_CHUNK / 24);
+    const int64_t chunks = (n + ROWS - 1) / ROWS;
+    std::vector<int64_t> at((size_t)chunks + 1, 0);
+    {
+        const int T = (int)std::min<int64_t>(host_threads(0), std::max<int64_t>(chunks, 1));
+        host_parallel(T, [&](int t) {
+            for (int64_t c = t; c < chunks; c += T) {
+                const int64_t r0 = c * ROWS, r1 = std::min(n, r0 + ROWS);
+                int64_t k = 0;
+                for (int64_t i = r0; i < r1; i++) {
+                    const double z = xyz[3 * i + 2];
+                    k += (z >= lo && z <= hi) ? 1 : 0;
+                }
+                at[(size_t)c + 1] = k;
+            }
+        });
+    }
+    for (int64_t c = 0; c < chunks; c++)
+        at[(size_t)c + 1] += at[(size_t)c];
+    *kept = at[(size_t)chunks];
+    PCFIT_TRY(out.alloc((size_t)*kept * 24));
+    if (*kept == 0)
+        return PCFIT_OK;
+    int dev = 0;
+    PCFIT_HIP(hipGetDevice(&dev));
+    std::unique_lock<std::mutex> lock(g_stage_mu);
+    if (!stage_make(dev)) {
+        set_error("upload of a z range: no pinned staging buffers");
+        return PCFIT_ERR_HIP;
+    }
+    PCFIT_HIP(hipStreamSynchronize(nullptr));
+    int rc[STAGE_T] = {};
+    auto work = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { rc[t] = 1; return; }
+        size_t use = 0;
+        for (int64_t c = t; c < chunks; c += STAGE_T) {
+            const int64_t rows = at[(size_t)c + 1] - at[(size_t)c];
+            if (rows == 0)
+                continue;
+            const int b = 2 * t + (int)(use & 1);
+            if (use >= 2 && hipEventSynchronize(g_stage.ev[b]) != hipSuccess) { rc[t] = 1; return; }
+            use++;
+            double *dstp = static_cast<double *>(g_stage.buf[b]);
+            const int64_t r0 = c * ROWS, r1 = std::min(n, r0 + ROWS);
+            for (int64_t i = r0; i < r1; i++) {
+                const double z = xyz[3 * i + 2];
+                if (z >= lo && z <= hi) {
+                    dstp[0] = xyz[3 * i];
+                    dstp[1] = xyz[3 * i + 1];
+                    dstp[2] = z;
+                    dstp += 3;
+                }
+            }
+            if (hipMemcpyAsync(out.as<char>() + (size_t)at[(size_t)c] * 24, g_stage.buf[b], (size_t)rows * 24,
+                               hipMemcpyHostToDevice, g_stage.st[t]) != hipSuccess ||
+                hipEventRecord(g_stage.ev[b], g_stage.st[t]) != hipSuccess) { rc[t] = 1; return; }
+        }
+        if (hipStreamSynchronize(g_stage.st[t]) != hipSuccess)
+            rc[t] = 1;
+    };
+    std::thread pool[STAGE_T - 1];
+    for (int t = 1; t < STAGE_T; t++)
+        pool[t - 1] = std::thread(work, t);
+    work(0);
+    for (auto &th : pool)
+        th.join();
+    for (int t = 0; t < STAGE_T; t++)
+        if (rc[t]) {
+            (void)hipGetLastError();
+            set_error("staged upload of a z range failed");
+            return PCFIT_ERR_HIP;
+        }
+    return PCFIT_OK;
+}
+
 int pool_release()
 {
     {
@@ -366,6 +470,97 @@ int pool_release()
 
 using namespace pcfit;
 
+// ------------------------------------------------------------------ host passes over a scan's z column
+PCFIT_API int pcfit_host_z_range(const double *xyz, int64_t n_points, int32_t n_threads, double *z_min_max)
+{
+    PCFIT_REQUIRE(z_min_max && n_points >= 0 && (xyz || n_points == 0), "host_z_range: null pointer or negative size");
+    const double qnan = __builtin_nan("");
+    z_min_max[0] = z_min_max[1] = qnan;
+    if (n_points == 0)
+        return PCFIT_OK;
+    const int T = (int)std::min<int64_t>(host_threads(n_threads), std::max<int64_t>(1, n_points / 65536));
+    std::vector<double> lo((size_t)T, __builtin_inf()), hi((size_t)T, -__builtin_inf());
+    std::vector<int> bad((size_t)T, 0);
+    host_parallel(T, [&](int t) {
+        const int64_t r0 = n_points * t / T, r1 = n_points * (t + 1) / T;
+        double l = __builtin_inf(), h = -__builtin_inf();
+        int b = 0;
+        for (int64_t i = r0; i < r1; i++) {
+            const double z = xyz[3 * i + 2];
+            b |= (z != z);
+            l = z < l ? z : l;
+            h = z > h ? z : h;
+        }
+        lo[(size_t)t] = l;
+        hi[(size_t)t] = h;
+        bad[(size_t)t] = b;
+    });
+    double l = lo[0], h = hi[0];
+    int b = bad[0];
+    for (int t = 1; t < T; t++) {
+        l = std::min(l, lo[(size_t)t]);
+        h = std::max(h, hi[(size_t)t]);
+        b |= bad[(size_t)t];
+    }
+    if (!b) {
+        z_min_max[0] = l;
+        z_min_max[1] = h;
+    }
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_host_window_counts(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                       int64_t n_slices, int32_t n_threads, int64_t *counts)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1 && (xyz || n_points == 0) && z_lo && z_hi && counts,
+                  "host_window_counts: null pointer or bad size");
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
+    const int64_t S = n_slices;
+    const double width = geom[1] - geom[0];
+    const double step = S > 1 ? (geom[2] - geom[0]) / (double)(S - 1) : (width > 0 ? width : 1.0);
+    PCFIT_REQUIRE(step > 0 && std::isfinite(step), "host_window_counts: windows must be ascending with finite bounds");
+    const double inv_step = 1.0 / step, lo0 = geom[0];
+    const int T = (int)std::min<int64_t>(host_threads(n_threads), std::max<int64_t>(1, n_points / 65536));
+    std::vector<std::vector<int64_t>> part((size_t)T, std::vector<int64_t>((size_t)S, 0));
+    host_parallel(T, [&](int t) {
+        int64_t *c = part[(size_t)t].data();
+        const int64_t r0 = n_points * t / T, r1 = n_points * (t + 1) / T;
+        for (int64_t i = r0; i < r1; i++) {
+            const double z = xyz[3 * i + 2];
+            const double u = (z - lo0) * inv_step;
+            if (!(u > -2.0) || !(u < (double)S + 2.0))
+                continue;                                       // (NaN lands here too)
+            const int64_t k0 = (int64_t)floor(u);
+            for (int64_t k = std::max<int64_t>(k0 - 1, 0); k <= std::min<int64_t>(k0 + 1, S - 1); k++)
+                c[k] += (z >= z_lo[k] && z <= z_hi[k]) ? 1 : 0;
+        }
+    });
+    for (int64_t s = 0; s < S; s++) {
+        int64_t v = 0;
+        for (int t = 0; t < T; t++)
+            v += part[(size_t)t][(size_t)s];
+        counts[s] = v;
+    }
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_scan_upload_z_range(const double *xyz, int64_t n_points, double z_lo, double z_hi,
+                                        pcfit_scan **scan, int64_t *n_kept)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(scan && n_kept && n_points >= 0 && (xyz || n_points == 0),
+                  "scan_upload_z_range: null pointer or negative size");
+    *scan = nullptr;
+    std::unique_ptr<pcfit_scan> sc(new (std::nothrow) pcfit_scan);
+    PCFIT_REQUIRE(sc != nullptr, "scan_upload_z_range: out of host memory");
+    PCFIT_HIP(hipGetDevice(&sc->device));
+    PCFIT_TRY(upload_rows_in_z_range(xyz, n_points, z_lo, z_hi, sc->xyz, n_kept));
+    sc->n_points = *n_kept;
+    *scan = sc.release();
+    return PCFIT_OK;
+}
+
 // ------------------------------------------------------------------ plumbing
 PCFIT_API int pcfit_version(void) { return 100; }
 PCFIT_API const char *pcfit_last_error(void) { return g_err; }
@@ -381,6 +576,12 @@ PCFIT_API int pcfit_device_count(int *count)
 PCFIT_API int pcfit_set_device(int device)
 {
     PCFIT_HIP(hipSetDevice(device));
+    return PCFIT_OK;
+}
+PCFIT_API int pcfit_get_device(int *device)
+{
+    PCFIT_REQUIRE(device, "device is null");
+    PCFIT_HIP(hipGetDevice(device));
     return PCFIT_OK;
 }
 PCFIT_API int pcfit_malloc(void **ptr, size_t bytes)

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import numpy as np
 
+from .analyzer import _FIT
+
 
 def split_by_points(counts, world: int) -> np.ndarray:
     """Bounds (world + 1 entries) of contiguous slice ranges whose point totals
@@ -66,69 +68,152 @@ def allgather_slice_arrays(local, bounds, group=None):
     return out
 
 
+REC = 16        # doubles per window in the exchanged record (13 used)
+
+
+def pack_window_records(h):
+    """Per-window results of a hybrid batch as one (S, REC) float64 array - population, status, candidate
+    count, arg-max / arg-min candidate, fitted circle, the five ovality scalars - and the candidates as one
+    (2, n_cand) array.  Integers are exact in float64 (all far below 2^53)."""
+    S = len(h["status"])
+    rec = np.zeros((S, REC))
+    rec[:, 0] = np.diff(h["offsets"])
+    rec[:, 1] = h["status"]
+    rec[:, 2] = np.diff(h["cand_offsets"])
+    rec[:, 3] = h["argmax"]
+    rec[:, 4] = h["argmin"]
+    rec[:, 5:8] = h["fit"]
+    rec[:, 8:13] = h["ov"]
+    return rec, np.stack([h["cand_x"], h["cand_y"]])
+
+
+def unpack_window_records(rec, cand):
+    """Inverse of pack_window_records for any number of windows: the dict CylinderAnalyzer._window_results reads."""
+    S = rec.shape[0]
+    n0 = rec[:, 0].astype(np.int64)
+    nc = rec[:, 2].astype(np.int64)
+    offsets = np.zeros(S + 1, np.int64)
+    np.cumsum(n0, out=offsets[1:])
+    co = np.zeros(S + 1, np.int64)
+    np.cumsum(nc, out=co[1:])
+    return dict(offsets=offsets, status=rec[:, 1].astype(np.int32), cand_offsets=co,
+                cand_x=np.ascontiguousarray(cand[0]), cand_y=np.ascontiguousarray(cand[1]),
+                argmax=rec[:, 3].astype(np.int64), argmin=rec[:, 4].astype(np.int64),
+                fit=np.ascontiguousarray(rec[:, 5:8]), ov=np.ascontiguousarray(rec[:, 8:13]))
+
+
+def _collective_device(group):
+    """Where tensors of a collective must live: the calling thread's GPU under RCCL, host memory otherwise."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def allgather_window_records(rec, cand, bounds, group=None):
+    """Two fixed-size all-gathers (all_gather_into_tensor: RCCL on GPUs): the window records of every rank,
+    padded to the largest shard, then - their sizes known from the records - the candidates, padded to the
+    largest total.  Returns (records of all windows in window order, candidates (2, total))."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = np.diff(np.asarray(bounds, dtype=np.int64))
+    dev = _collective_device(group)
+    pad = max(int(sizes.max()), 1)
+    mine = torch.zeros((pad, REC), dtype=torch.float64)
+    mine[:rec.shape[0]] = torch.from_numpy(rec)
+    mine = mine.to(dev)
+    everyone = torch.empty((world * pad, REC), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    everyone = everyone.cpu().numpy().reshape(world, pad, REC)
+    recs = np.concatenate([everyone[r, :int(sizes[r])] for r in range(world)], axis=0)
+    totals = [int(everyone[r, :int(sizes[r]), 2].sum()) for r in range(world)]
+    cpad = max(max(totals), 1)
+    mine_c = torch.zeros((2, cpad), dtype=torch.float64)
+    mine_c[:, :cand.shape[1]] = torch.from_numpy(np.ascontiguousarray(cand))
+    mine_c = mine_c.to(dev)
+    every_c = torch.empty((world * 2, cpad), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(every_c, mine_c, group=group)
+    every_c = every_c.cpu().numpy().reshape(world, 2, cpad)
+    cands = np.concatenate([every_c[r, :, :totals[r]] for r in range(world)], axis=1)
+    return recs, cands
+
+
 def analyze_sharded(analyzer, points, group=None, progress_callback=None):
     """CylinderAnalyzer.analyze_with_progress with the windows sharded over the
-    ranks of ``group``: every rank bins and fits its own range of windows on its
-    GPU, then the per-slice result dicts are exchanged so that every rank returns
-    the full, z-ordered list.  ``points`` is the whole scan on every rank, as an
-    (N, 3) array or a DeviceScan already on the rank's GPU."""
+    ranks of ``group``: every rank takes a contiguous range of windows balanced
+    by point count, uploads ONLY the rows of the scan whose z lies in that range
+    (closed edges: a point on the edge shared with the neighbouring rank goes to
+    both), bins and fits them on its GPU, and the per-window records (fit,
+    metrics, candidates) are exchanged with two fixed-size all-gathers, so that
+    every rank returns the full, z-ordered list - the same dicts, bit for bit, as
+    a single rank computes.  ``points`` is the whole scan on every rank, as an
+    (N, 3) array, or a DeviceScan already on the rank's GPU.  The work runs on
+    the device that is current in the calling thread (one process per GPU: select
+    it with torch.cuda.set_device(local_rank) or pcfit_set_device before the
+    call)."""
     import torch.distributed as dist
 
+    from . import _ffi
     from ._ffi import DeviceScan
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dz = analyzer.config.z_step / 2.0
     ranged = analyzer.z_min is not None and analyzer.z_max is not None
-    if isinstance(points, DeviceScan) or not ranged:
-        # The scan goes to this rank's GPU once, whole: the z range, the window populations (the count pass of
-        # the binning) and the analysis of the rank's own windows all read that copy, and points of other ranks'
-        # windows are simply never binned. No pass over the points on the host.
-        own = not isinstance(points, DeviceScan)
-        if own:
-            points = np.ascontiguousarray(points, dtype=np.float64)
-            if points.ndim != 2 or points.shape[1] != 3:
-                raise ValueError("Points must be Nx3 array")
-        elif ranged:
+    resident = isinstance(points, DeviceScan)
+    if resident:
+        if ranged:
             raise ValueError("a DeviceScan cannot be combined with Config.z_min / z_max: pass the array")
-        scan = DeviceScan(points) if own and len(points) else points
-        try:
-            z_centers = analyzer.calculate_z_centers(scan)
-            counts = (scan.window_counts(z_centers - dz, z_centers + dz) if len(z_centers) and len(scan)
-                      else np.zeros(len(z_centers), np.int64))
-            bounds = split_by_points(counts, world)
-            s0, s1 = shard_range(bounds, rank)
-            mine = []
-            if s1 > s0:
-                for res, _, warn in analyzer._analyze_windows(scan, z_centers[s0:s1]):
-                    if warn is None:
-                        mine.append(res)
-        finally:
-            if own and isinstance(scan, DeviceScan):
-                scan.close()
+        z_centers = analyzer.calculate_z_centers(points)
+        counts = (points.window_counts(z_centers - dz, z_centers + dz) if len(z_centers) and len(points)
+                  else np.zeros(len(z_centers), np.int64))
     else:
-        # a configured z range filters the points first (analyzer.py:190-196), which needs the array
         points = np.ascontiguousarray(points, dtype=np.float64)
         if points.ndim != 2 or points.shape[1] != 3:
             raise ValueError("Points must be Nx3 array")
-        points = points[(points[:, 2] >= analyzer.z_min) & (points[:, 2] <= analyzer.z_max)]
-        if len(points) == 0:
-            raise ValueError(f"No points in specified Z range [{analyzer.z_min}, {analyzer.z_max}]")
-        z_centers = analyzer.calculate_z_centers(points)
-        # balance by the window populations (one histogram of z on the host)
-        edges = np.concatenate([z_centers - dz, z_centers[-1:] + dz]) if len(z_centers) else np.zeros(1)
-        counts = np.histogram(points[:, 2], bins=edges)[0] if len(z_centers) else np.zeros(0, np.int64)
-        bounds = split_by_points(counts, world)
-        s0, s1 = shard_range(bounds, rank)
-        mine = []
-        if s1 > s0:
-            lo, hi = z_centers[s0] - dz, z_centers[s1 - 1] + dz
-            sel = points[(points[:, 2] >= lo) & (points[:, 2] <= hi)]
-            for res, _, warn in analyzer._analyze_windows(np.ascontiguousarray(sel), z_centers[s0:s1]):
-                if warn is None:
-                    mine.append(res)
-    everyone = [None] * world
-    dist.all_gather_object(everyone, mine, group=group)
-    results = [r for part in everyone for r in part]
+        if ranged:
+            z_lo_all, z_hi_all = analyzer.z_min, analyzer.z_max
+        elif len(points):
+            # (calculate_z_centers would make two strided numpy passes over the z column)
+            z_lo_all, z_hi_all = (np.float64(v) for v in _ffi.host_z_range(points))
+        else:
+            z_lo_all = z_hi_all = np.float64("nan")
+        z_centers = np.arange(z_lo_all + dz, z_hi_all - dz + 1e-9, analyzer.config.z_step)
+        counts = (_ffi.host_window_counts(points, z_centers - dz, z_centers + dz) if len(z_centers) and len(points)
+                  else np.zeros(len(z_centers), np.int64))
+        if ranged and counts.sum() == 0:
+            # the reference filters by the configured range first and refuses an empty result (analyzer.py:190-196)
+            z = points[:, 2]
+            if not np.any((z >= analyzer.z_min) & (z <= analyzer.z_max)):
+                raise ValueError(f"No points in specified Z range [{analyzer.z_min}, {analyzer.z_max}]")
+    S = len(z_centers)
+    bounds = split_by_points(counts, world)
+    s0, s1 = shard_range(bounds, rank)
+    empty = dict(offsets=np.zeros(1, np.int64), status=np.zeros(0, np.int32), cand_offsets=np.zeros(1, np.int64),
+                 cand_x=np.zeros(0), cand_y=np.zeros(0), argmax=np.zeros(0, np.int64), argmin=np.zeros(0, np.int64),
+                 fit=np.zeros((0, 3)), ov=np.zeros((0, 5)))
+    h = empty
+    if s1 > s0:
+        lo, hi = z_centers[s0:s1] - dz, z_centers[s0:s1] + dz
+        args = (_FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None, _FIT["huber_delta"],
+                _FIT["use_hull"])
+        if resident:
+            h = _ffi.scan_hybrid_batch(points, lo, hi, *args)
+        else:
+            with DeviceScan(points, z_range=(lo[0], hi[-1])) as part:
+                if len(part):
+                    h = _ffi.scan_hybrid_batch(part, lo, hi, *args)
+                else:
+                    h = dict(empty, offsets=np.zeros(s1 - s0 + 1, np.int64), status=np.ones(s1 - s0, np.int32),
+                             cand_offsets=np.zeros(s1 - s0 + 1, np.int64), argmax=np.zeros(s1 - s0, np.int64),
+                             argmin=np.zeros(s1 - s0, np.int64), fit=np.full((s1 - s0, 3), np.nan),
+                             ov=np.full((s1 - s0, 5), np.nan))
+    rec, cand = pack_window_records(h)
+    recs, cands = allgather_window_records(rec, cand, bounds, group)
+    assert recs.shape[0] == S
+    results = [res for res, _, warn in analyzer._window_results(z_centers, unpack_window_records(recs, cands), False)
+               if warn is None]
     results.sort(key=lambda r: r["z_center"])
     if progress_callback:
         progress_callback(100)
@@ -150,6 +235,7 @@ def analyze_scans_sharded(analyzer, scans, group=None, progress_callback=None, g
     Without an initialised process group the one caller takes every scan."""
     from concurrent.futures import ThreadPoolExecutor
 
+    from . import _ffi
     from ._ffi import DeviceScan
 
     world, rank = 1, 0
@@ -162,8 +248,13 @@ def analyze_scans_sharded(analyzer, scans, group=None, progress_callback=None, g
     except ImportError:
         pass
     mine = scans_of_rank(len(scans), rank, world)
+    # The upload thread below starts on device 0 whatever this thread has selected (the current device is a
+    # property of the thread), and a scan can only be analysed on the device it was uploaded to: hand the
+    # caller's device over.
+    device = _ffi.current_device()
 
     def resident(k):
+        _ffi.set_device(device)
         item = scans[k]
         pts = item() if callable(item) else item
         pts = np.ascontiguousarray(pts, dtype=np.float64)

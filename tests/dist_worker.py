@@ -28,18 +28,57 @@ def main():
             got = sharding.allgather_slice_arrays([torch.from_numpy(fit_all[s0:s1].copy()),
                                                    torch.from_numpy(hist_all[s0:s1].copy())], bounds)
             ok &= np.array_equal(got[0].numpy(), fit_all) and np.array_equal(got[1].numpy(), hist_all)
-    elif mode == "analyze_gpu":
+    elif mode == "records":
+        # the packed per-window records and the two fixed-size gathers, on made-up results (no GPU)
+        gen = np.random.default_rng(7)                         # same stream on every rank
+        for S in (0, 1, 2, 9, 57):
+            n0 = gen.integers(0, 9000, S)
+            nc = gen.integers(0, 200, S) * (gen.random(S) < 0.8)
+            co = np.concatenate([[0], np.cumsum(nc)]).astype(np.int64)
+            full = dict(offsets=np.concatenate([[0], np.cumsum(n0)]).astype(np.int64),
+                        status=gen.integers(0, 4, S).astype(np.int32), cand_offsets=co,
+                        cand_x=gen.normal(size=co[-1]), cand_y=gen.normal(size=co[-1]),
+                        argmax=gen.integers(0, 100, S), argmin=gen.integers(0, 100, S),
+                        fit=gen.normal(size=(S, 3)), ov=gen.normal(size=(S, 5)))
+            if S:
+                full["fit"][0, 1] = np.nan                     # a failed window travels as NaN
+            bounds = sharding.split_by_points(n0, world)
+            s0, s1 = sharding.shard_range(bounds, rank)
+            mine = dict(offsets=full["offsets"][s0:s1 + 1] - full["offsets"][s0], status=full["status"][s0:s1],
+                        cand_offsets=co[s0:s1 + 1] - co[s0], cand_x=full["cand_x"][co[s0]:co[s1]],
+                        cand_y=full["cand_y"][co[s0]:co[s1]], argmax=full["argmax"][s0:s1],
+                        argmin=full["argmin"][s0:s1], fit=full["fit"][s0:s1], ov=full["ov"][s0:s1])
+            rec, cand = sharding.pack_window_records(mine)
+            recs, cands = sharding.allgather_window_records(rec, cand, bounds)
+            got = sharding.unpack_window_records(recs, cands)
+            for k, v in full.items():
+                ok &= np.array_equal(got[k], v, equal_nan=True) and got[k].dtype == np.asarray(v).dtype
+    elif mode in ("analyze_gpu", "analyze_gpu_ranged"):
         from oracle import ref_np as R
-        from pointcloud_amd import Config, CylinderAnalyzer
-        pts = R.make_cylinder(60_000, 12, seed=17, outlier_frac=0.0)
-        az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500))
+        from pointcloud_amd import Config, CylinderAnalyzer, DeviceScan
+        pts = R.make_cylinder(60_000, 12, seed=17, outlier_frac=0.02)
+        # points exactly on window edges, shared ones included: they belong to two windows, and where the
+        # two windows belong to two ranks both ranks must have uploaded them
+        for k, zc in enumerate(np.arange(0.0, 24.5, 2.0)):
+            pts[100 + 5 * k:105 + 5 * k, 2] = zc
+        if mode == "analyze_gpu":
+            az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500))
+            want_windows = 12
+        else:
+            az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500, z_min=3.0, z_max=20.0))
+            want_windows = 8
         res = sharding.analyze_sharded(az, pts)
-        if rank == 0:
-            single = az.analyze_with_progress(pts)
-            ok &= len(res) == len(single) == 12
-            for a, b in zip(res, single):
-                ok &= a["z_center"] == b["z_center"] and a["cx"] == b["cx"] and a["R"] == b["R"]
-                ok &= a["boundary_points"] == b["boundary_points"] and a["n_points_slice"] == b["n_points_slice"]
+        single = az.analyze_with_progress(pts)
+        ok &= len(res) == len(single) == want_windows
+        ok &= res == single                                    # every key of every dict, floats bit for bit
+        if mode == "analyze_gpu":
+            with DeviceScan(pts) as scan:                      # a scan that is already on the rank's GPU, whole
+                ok &= sharding.analyze_sharded(az, scan) == single
+            # a rank whose range holds no window, and windows that are all too sparse
+            few = CylinderAnalyzer(Config(z_step=12.0, min_points_per_slice=500))
+            ok &= sharding.analyze_sharded(few, pts) == few.analyze_with_progress(pts)
+            sparse = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=10**6))
+            ok &= sharding.analyze_sharded(sparse, pts) == []
     elif mode == "scans_gpu":
         from oracle import ref_np as R
         from pointcloud_amd import Config, CylinderAnalyzer

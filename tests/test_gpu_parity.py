@@ -379,6 +379,28 @@ def test_process_slice_contract():
         CylinderAnalyzer(Config(z_min=1e6, z_max=2e6)).analyze_with_progress(pts)
 
 
+def test_process_slice_thins_what_it_hands_back_not_what_it_fits():
+    """analyzer.py:56-60: a window of more than max_points_for_speed points is thinned (unseeded choice) for the
+    caller's plot and for n_points_slice only; the fit sees every point."""
+    from pointcloud_amd import Config, CylinderAnalyzer
+    pts = R.make_slab(6000, 91, outlier=0.01, half_height=0.99)
+    capped = CylinderAnalyzer(Config(min_points_per_slice=100, max_points_for_speed=1500)).process_slice(pts, 0.0)
+    whole = CylinderAnalyzer(Config(min_points_per_slice=100)).process_slice(pts, 0.0)
+    (res_c, cand_c, slc_c, fit_c, ov_c), edge_c, warn_c = capped
+    (res_w, cand_w, slc_w, fit_w, ov_w), edge_w, warn_w = whole
+    assert warn_c is None and warn_w is None
+    assert res_c["n_points_slice"] == 1500 and res_w["n_points_slice"] == 6000
+    assert slc_c.shape == (1500, 2) and slc_w.shape == (6000, 2)
+    assert set(map(tuple, slc_c)) <= set(map(tuple, slc_w)) and len(set(map(tuple, slc_c))) == 1500
+    assert fit_c == fit_w and np.array_equal(cand_c, cand_w)
+    for k in res_w:
+        if k != "n_points_slice":
+            assert res_c[k] == res_w[k], k
+    # too sparse: decided before any fit is run
+    none = CylinderAnalyzer(Config(min_points_per_slice=7000)).process_slice(pts, 0.0)
+    assert none == (None, None, "SKIP zc=0.000: too sparse (6000 points)")
+
+
 def test_dropin_function_contracts():
     from pointcloud_amd.utils import circle_fitting as CF
     from pointcloud_amd.utils import boundary as B
