@@ -217,6 +217,32 @@ struct SliceView {
         }
     }
 
+    // the first full group alone (what full_groups() would hand out first); false when the slice has none
+    template <class FG>
+    __device__ __forceinline__ bool first_group(FG &&fg) const
+    {
+        constexpr int U = GROUP;
+        if (U * FIT_BLOCK > n)
+            return false;
+        double px[U], py[U];
+        if constexpr (STREAM) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                px[u] = xs[u * FIT_BLOCK + threadIdx.x];
+                py[u] = ys[u * FIT_BLOCK + threadIdx.x];
+            }
+        } else {
+            static_assert(PT_R >= U, "the first group lives in registers");
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                px[u] = rx[u];
+                py[u] = ry[u];
+            }
+        }
+        fg(px, py, (int32_t)threadIdx.x);
+        return true;
+    }
+
     template <class FG>
     __device__ __forceinline__ void ragged_group(FG &&fg) const
     {
@@ -280,9 +306,9 @@ __device__ __forceinline__ void each_point(const View &P, F &&f)
 }
 
 // Static LDS of a fit kernel, in doubles: two scratch areas for the workgroup
-// reductions (13 values x 16 waves each, used alternately) and two areas for
-// totals (12 sums and a minimum).
-constexpr int RED_SCR = 13 * 16, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 32;
+// reductions (14 values x 16 waves each, used alternately) and two areas for
+// totals (12 sums, the smallest and the largest distance).
+constexpr int RED_SCR = 14 * 16, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 32;
 
 // Where the next reduction of a workgroup puts its partial sums.  Alternating
 // between two scratch areas (and never writing totals that may still be read)
@@ -354,8 +380,8 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
 //    when a rejected candidate equals the current parameters bit for bit.
 //    The iteration count the literal loop would have reached is reported.
 template <int NW, class View>
-__device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedCtx &red, double par[3],
-                                         int32_t iters[4], Phase &ph)
+__device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedCtx &red, double par[3],
+                                         int32_t iters[4], Phase &ph, double reach[2])
 {
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
     const double delta = prm.delta;
@@ -364,7 +390,7 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
     // Huber-weighted problem, the curvature sum and the Huber cost, all from the same distances.
     //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
     //   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones
-    // The totals of a sweep stay in LDS (tot: 12 sums, then the smallest distance): they are the
+    // The totals of a sweep stay in LDS (tot: 12 sums, then the smallest and the largest distance): they are the
     // same for every thread, and keeping two sets of them in registers would cost 48 VGPRs per lane.
     //
     // Two forms of the pass.  The short one takes every point for a regular one: at a distance
@@ -377,11 +403,11 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
     auto sweep = [&](double px0, double py0, double pr, double *tot) {
         constexpr int U = View::GROUP;
         double acc[12];
-        double low;
+        double low, high;
         auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
 #pragma unroll
             for (int u = 0; u < U; u++)
-                lm_point_general(acc, low, px[u], py[u], px0, py0, pr, delta, root_delta,
+                lm_point_general(acc, low, high, px[u], py[u], px0, py0, pr, delta, root_delta,
                                  !check || i0 + u * View::STRIDE < P.n);
         };
         auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, true); };
@@ -390,23 +416,23 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
             for (int k = 0; k < 12; k++)
                 acc[k] = 0.0;
             low = inf;
-            double amax = 0.0;                  // largest |residual| seen
+            high = -inf;
             P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const double dx = px[u] - px0, dy = py[u] - py0;
                     const double d2 = fma(dx, dx, dy * dy);
-                    const double y0 = rsqrt_nr(d2);
-                    const double ri = fma(d2, y0, 1e-16);
-                    const double iv = fma(-1e-16 * y0, y0, y0);
+                    // 1 / (sqrt(d2) + 1e-16) is taken as 1 / sqrt(d2): they differ by 1e-16 / ri relatively, below
+                    // one rounding from ri = 0.5 on, and the form is left when a distance falls below 1e-6
+                    const double iv = rsqrt_nr(d2);
+                    const double ri = fma(d2, iv, 1e-16);
                     const double r = ri - pr;
-                    amax = max_abs_no_nan(amax, r);
+                    high = max_no_nan(high, ri);
                     const double j0 = -dx * iv, j1 = -dy * iv;
                     acc[10] = fma(r, r, acc[10]);
                     acc[0] = fma(j0, j0, acc[0]);
                     acc[1] = fma(j0, j1, acc[1]);
                     acc[2] = acc[2] - j0;
-                    acc[3] = fma(j1, j1, acc[3]);
                     acc[4] = acc[4] - j1;
                     acc[6] = fma(j0, r, acc[6]);
                     acc[7] = fma(j1, r, acc[7]);
@@ -417,12 +443,15 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
             });
             // a point was not regular: a residual beyond the threshold, or a NaN (which a distance of
             // zero gives here as well) that the sum of squares has kept
-            const bool odd = !(amax <= delta) || acc[10] != acc[10];
+            // (the largest |residual| sits at the largest or at the smallest distance; without points -inf)
+            const double amax = max_no_nan(high - pr, pr - low);
+            const bool odd = !(amax <= delta) || acc[10] != acc[10] || low < 1e-6;
             acc[5] = (double)P.full_points_per_thread();      // the sum of that many ones (j2 = -1)
+            acc[3] = acc[5] - acc[0];                           // j0^2 + j1^2 = d2 / d2 = 1 for every point
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);
-            block_reduce_to_lds<12, true, NW>(acc, low, red.scratch(), tot);
+            block_reduce_to_lds2<12, NW>(acc, low, high, red.scratch(), tot);
             ph.mark(3);
             if (tot[12] != -inf)
                 return;
@@ -432,10 +461,11 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
         for (int k = 0; k < 12; k++)
             acc[k] = 0.0;
         low = inf;
+        high = -inf;
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false); });
         P.ragged_group(ragged);
         ph.mark(2);
-        block_reduce_to_lds<12, true, NW>(acc, low, red.scratch(), tot);
+        block_reduce_to_lds2<12, NW>(acc, low, high, red.scratch(), tot);
         ph.mark(3);
     };
 
@@ -449,6 +479,11 @@ __device__ __forceinline__ void lm_slice(const View &P, const LmParams prm, RedC
     }
     lm_finish(st, par, iters);
     ph.mark(4);
+    // smallest and largest distance (sqrt + 1e-16) of the slice's points from the returned centre: known when a
+    // sweep ran at exactly these parameters
+    reach[0] = st.min_ri;
+    reach[1] = st.max_ri;
+    return st.cur >= 0;
 }
 
 template <int PT_R, int PT_L, int FIT_BLOCK>
@@ -489,7 +524,8 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void lm_kernel(const double *__restri
     P.load(x, y, off, n);
     double c[3] = {init[3 * s], init[3 * s + 1], init[3 * s + 2]};
     int32_t it[4] = {0, 0, 0, 0};
-    lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
+    double reach[2];
+    lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph, reach);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -526,8 +562,9 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_kernel(const double *__restr
         kasa_out[3 * s + 2] = c[2];
     }
     int32_t it[4] = {0, 0, 0, 0};
+    double reach[2];
     if (st != PCFIT_ST_SPARSE)
-        lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
+        lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph, reach);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
@@ -559,81 +596,172 @@ __device__ __forceinline__ Extreme2 better_min(Extreme2 a, Extreme2 b)
     return (b.r < a.r || (b.r == a.r && b.i < a.i)) ? b : a;
 }
 
+// Number of copies of the LDS histogram (lanes spread their updates over them by lane number, which
+// cuts the serialisation of lanes that hit one counter) and the distance between copies, in counters
+// (the extra 8 put the copies on different banks).
+__host__ __device__ __forceinline__ int hist_copies(int32_t H) { return H <= 512 ? 4 : 1; }
+__host__ __device__ __forceinline__ int hist_stride(int32_t H) { return H + 8; }
+
 // Residual statistics of one slice about the circle (cx, cy, R): histogram of
 // dr = hypot - R (numpy.histogram rules, H bins), Rmax / Rmin and the first
 // index attaining each (analyzer.py:83-92, gui.py:979-983).  The H+1 edges are
-// in LDS at lds_dyn[base ..], the H int32 counters (zeroed by the caller) follow.
+// in LDS at lds_dyn[base ..], the int32 counters (hist_copies(H) copies,
+// hist_stride(H) apart, zeroed by the caller) follow.
+//
+// Results are those of the correctly rounded hypot (cr_hypot) for every point,
+// but only the points that need it pay for it.  A point's radius is first taken
+// from the reciprocal square root (r1, within 4.7e-16 of the exact value,
+// relatively); its bin follows from t = (r1 - R - e0) * H / (eH - e0) whenever t
+// is farther than 2^-20 from an integer - the caller has checked that the edges
+// are uniform to a quarter of that (edges_uniform), and the errors of r1 and of
+// t stay below another quarter - and it can only be an extreme when r1 comes
+// within 3e-15 of the slice's largest / smallest distance from the centre.  Those
+// two are known from the last LM sweep when it ran at exactly this centre
+// (reach); otherwise the largest and smallest r1 of the slice's first group of
+// points stand in for them (every point beyond them is then examined).  The
+// points for which either test fails (a handful of 8192) go through the exact
+// code: cr_hypot, numpy's guess-and-repair against the edges, and the (radius,
+// first index) comparison.  Slices whose parameters leave no such margins, and
+// the ragged end of every slice, take the exact code for all points.
 template <class View>
 __device__ __forceinline__ void residual_slice(const View &P, double cx, double cy, double R, int32_t H, int32_t base,
                                                int64_t s, int64_t *__restrict__ hist, double *__restrict__ rmax_rmin,
-                                               int64_t *__restrict__ argmax_argmin, Extreme2 *wmax, Extreme2 *wmin)
+                                               int64_t *__restrict__ argmax_argmin, Extreme2 *wmax, Extreme2 *wmin,
+                                               double *wthr /* 2 * 16 doubles */, bool edges_uniform, bool have_reach,
+                                               const double reach[2])
 {
+    using mask_t = unsigned long long;
     const double e0 = H > 0 ? lds_dyn[base] : 0.0, eH = H > 0 ? lds_dyn[base + H] : 0.0;
     // numpy.histogram puts d into the bin b with edges[b] <= d < edges[b+1] (last bin closed): it
     // guesses b by scaling and repairs the guess against the edges.  Any guess within one bin of the
     // truth gives the same b, so the guess here multiplies by H / span instead of dividing.
     const double scale = (double)H / (eH - e0);
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int32_t cnt0 = 2 * (base + H + 1) + (lane & (hist_copies(H) - 1)) * hist_stride(H);   // this lane's copy
     Extreme2 mx{-inf, -1}, mn{inf, -1};
-    // A group of U points: everything up to the bin numbers is computed for all of them without a
-    // branch, so that their dependency chains interleave; the counter updates come last.  HIST and
-    // CHECK (points past the end of the slice do not count) are compile-time so that the pass over the
-    // full groups carries neither test.
     constexpr int U = View::GROUP;
-    auto pass = [&](const double (&px)[U], const double (&py)[U], int32_t i0, auto hist_tag, auto check_tag) {
-        constexpr bool HIST = decltype(hist_tag)::value, CHECK = decltype(check_tag)::value;
-        double r[U];
-        bool valid[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            r[u] = cr_hypot(px[u] - cx, py[u] - cy);
-            valid[u] = !CHECK || i0 + u * View::STRIDE < P.n;
+    // the exact code for one point
+    auto exact_point = [&](double px, double py, int32_t i, bool valid, bool want_hist) {
+        const double r = cr_hypot(px - cx, py - cy);
+        const bool up = valid & (r > mx.r), dn = valid & (r < mn.r);       // strict: the first index stays
+        mx.r = up ? r : mx.r;
+        mn.r = dn ? r : mn.r;
+        mx.i = up ? i : mx.i;
+        mn.i = dn ? i : mn.i;
+        if (want_hist) {
+            // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
+            const double d = r - R;
+            const bool in = valid & (d >= e0) & (d <= eH);
+            const int32_t guess = (int32_t)((d - e0) * scale);
+            const int32_t g = max(0, min(guess, H - 1));
+            const double below = lds_dyn[base + g], above = lds_dyn[base + g + 1];
+            const bool under = d < below, over = !under & (g < H - 1) & (d >= above);
+            const int32_t b = g + (over ? 1 : 0) - (under ? 1 : 0);
+            if (in)
+                atomicAdd(reinterpret_cast<int32_t *>(lds_dyn) + cnt0 + b, 1);
         }
-        int32_t b[U];
-        bool in[U];
-        if constexpr (HIST) {
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                // (the LDS arrays are named through lds_dyn here: a captured pointer loses its address space)
-                const double d = r[u] - R;
-                in[u] = valid[u] & (d >= e0) & (d <= eH);
-                const int32_t guess = (int32_t)((d - e0) * scale);
-                const int32_t g = max(0, min(guess, H - 1));
-                const double below = lds_dyn[base + g], above = lds_dyn[base + g + 1];
-                const bool under = d < below, over = !under & (g < H - 1) & (d >= above);
-                b[u] = g + (over ? 1 : 0) - (under ? 1 : 0);
-            }
-        }
+    };
+    auto exact_group = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int32_t i = i0 + u * View::STRIDE;
-            const bool up = valid[u] & (r[u] > mx.r), dn = valid[u] & (r[u] < mn.r);   // strict: the first index stays
-            if constexpr (CHECK) {
-                mx.r = up ? r[u] : mx.r;
-                mn.r = dn ? r[u] : mn.r;
-            } else {
-                mx.r = max_no_nan(mx.r, r[u]);
-                mn.r = min_no_nan(mn.r, r[u]);
-            }
-            mx.i = up ? i : mx.i;
-            mn.i = dn ? i : mn.i;
-        }
-        if constexpr (HIST) {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (in[u])
-                    atomicAdd(reinterpret_cast<int32_t *>(lds_dyn + base + H + 1) + b[u], 1);
+            exact_point(px[u], py[u], i, !check || i < P.n, H > 0);
         }
     };
-    using Yes = std::true_type;
-    using No = std::false_type;
+
+    constexpr double TAU = 9.5367431640625e-07;              // 2^-20, in bins
+    // the margins of the bin test: uniform edges, and the errors of r1 (4.7e-16 r) and of the fused
+    // multiply-add that makes t within a quarter of TAU, in bins
+    bool fast = true;
     if (H > 0) {
-        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, Yes{}, No{}); });
-        P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, Yes{}, Yes{}); });
-    } else {
-        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, No{}, No{}); });
-        P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, No{}, Yes{}); });
+        const double span = fabs(R) + fmax(fabs(e0), fabs(eH));
+        fast = edges_uniform && scale > 0.0 && scale < inf && span * scale * 8.9e-16 <= 0.25 * TAU;
     }
+    // what an extreme has to reach (uniform over the workgroup)
+    double t_hi, t_lo;
+    if (have_reach) {
+        t_hi = (reach[1] - 2e-16) * (1.0 - 3e-15);
+        t_lo = (reach[0] + 2e-16) * (1.0 + 3e-15);
+    } else {
+        double m_hi = -inf, m_lo = inf;
+        const bool sampled = fast && P.first_group([&](const double (&px)[U], const double (&py)[U], int32_t) {
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double dx = px[u] - cx, dy = py[u] - cy;
+                const double d2 = fma(dx, dx, dy * dy);
+                const double r1 = d2 * rsqrt_nr(d2);
+                m_hi = max_no_nan(m_hi, r1);
+                m_lo = min_no_nan(m_lo, r1);
+            }
+        });
+        if (sampled) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) {
+                m_hi = max_no_nan(m_hi, __shfl_xor(m_hi, m, WAVE));
+                m_lo = min_no_nan(m_lo, __shfl_xor(m_lo, m, WAVE));
+            }
+            if (lane == 0) {
+                wthr[wave] = m_hi;
+                wthr[16 + wave] = m_lo;
+            }
+            __syncthreads();
+            for (int w = 0; w < nw; w++) {
+                m_hi = max_no_nan(m_hi, wthr[w]);
+                m_lo = min_no_nan(m_lo, wthr[16 + w]);
+            }
+        }
+        fast = sampled;
+        t_hi = m_hi * (1.0 - 2e-15);
+        t_lo = m_lo * (1.0 + 2e-15);
+    }
+    if (fast) {
+        const double c0 = -(R + e0) * scale;
+        auto pass = [&](const double (&px)[U], const double (&py)[U], int32_t i0, auto hist_tag) {
+            constexpr bool HIST = decltype(hist_tag)::value;
+            // conditions live as wave masks (scalar registers): one mask per point of the group
+            mask_t odd[U];
+            int32_t b[U];
+            mask_t any = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const double dx = px[u] - cx, dy = py[u] - cy;
+                const double d2 = fma(dx, dx, dy * dy);
+                const double r1 = d2 * rsqrt_nr(d2);
+                // (negated compares: a NaN radius - a point on the centre, an overflow - goes to the exact code)
+                mask_t o = __builtin_amdgcn_ballot_w64(!(r1 < t_hi)) | __builtin_amdgcn_ballot_w64(!(r1 > t_lo));
+                if constexpr (HIST) {
+                    const double t = fma(r1, scale, c0);
+                    const double ft = floor(t);
+                    o |= __builtin_amdgcn_ballot_w64(fabs((t - ft) - 0.5) > 0.5 - TAU);
+                    // counter H of a copy is nobody's bin: points outside the range, and the points that
+                    // the exact code counts, add their one there (no branch around the update)
+                    const uint32_t bin = min((uint32_t)(int32_t)ft, (uint32_t)H);
+                    b[u] = __builtin_amdgcn_inverse_ballot_w64(o) ? H : (int32_t)bin;
+                }
+                odd[u] = o;
+                any |= o;
+            }
+            if (any) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (__builtin_amdgcn_inverse_ballot_w64(odd[u]))
+                        exact_point(px[u], py[u], i0 + u * View::STRIDE, true, HIST);
+            }
+            if constexpr (HIST) {
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    atomicAdd(reinterpret_cast<int32_t *>(lds_dyn) + cnt0 + b[u], 1);
+            }
+        };
+        if (H > 0)
+            P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, std::true_type{}); });
+        else
+            P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { pass(px, py, i0, std::false_type{}); });
+    } else {
+        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, false); });
+    }
+    P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, true); });
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         Extreme2 o;
@@ -644,16 +772,20 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
         o.i = __shfl_xor(mn.i, m, WAVE);
         mn = better_min(mn, o);
     }
-    if ((threadIdx.x & 63) == 0) {
-        wmax[threadIdx.x >> 6] = mx;
-        wmin[threadIdx.x >> 6] = mn;
+    if (lane == 0) {
+        wmax[wave] = mx;
+        wmin[wave] = mn;
     }
     __syncthreads();
-    const int32_t *lhist = reinterpret_cast<const int32_t *>(lds_dyn + base + H + 1);
-    for (int b = threadIdx.x; b < H; b += blockDim.x)
-        hist[s * H + b] = (int64_t)lhist[b];
+    const int32_t *lhist = reinterpret_cast<const int32_t *>(lds_dyn) + 2 * (base + H + 1);
+    for (int b = threadIdx.x; b < H; b += blockDim.x) {
+        int32_t c = 0;
+        for (int k = 0; k < hist_copies(H); k++)
+            c += lhist[k * hist_stride(H) + b];
+        hist[s * H + b] = (int64_t)c;
+    }
     if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); w++) {
+        for (int w = 1; w < nw; w++) {
             mx = better_max(mx, wmax[w]);
             mn = better_min(mn, wmin[w]);
         }
@@ -675,6 +807,8 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
 {
     __shared__ double lds[RED_SIZE];
     __shared__ Extreme2 wmax[16], wmin[16];
+    __shared__ double wthr[2 * 16];
+    __shared__ int edges_off;           // set when the edges are not uniformly spaced
     Phase ph;
     ph.init();
     RedCtx red{lds, 0};
@@ -684,10 +818,24 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
     P.load(x, y, off, n);
     ph.mark(0);
     constexpr int base = SliceView<PT_R, PT_L, FIT_BLOCK>::LDS_DOUBLES;
-    for (int b = threadIdx.x; b < H; b += FIT_BLOCK)
-        reinterpret_cast<int32_t *>(lds_dyn + base + H + 1)[b] = 0;
+    if (threadIdx.x == 0)
+        edges_off = 0;
+    if (H > 0)
+        for (int b = threadIdx.x; b < hist_copies(H) * hist_stride(H); b += FIT_BLOCK)
+            reinterpret_cast<int32_t *>(lds_dyn + base + H + 1)[b] = 0;
     for (int b = threadIdx.x; b <= H && H > 0; b += FIT_BLOCK)
         lds_dyn[base + b] = edges[b];
+    __syncthreads();
+    if (H > 0) {
+        // uniform to 2^-22 of a bin: what lets residual_slice take a bin number from a product
+        const double e0 = edges[0], eH = edges[H];
+        const double width = (eH - e0) / (double)H, per_bin = (double)H / (eH - e0);
+        bool ok = true;
+        for (int b = threadIdx.x; b <= H; b += FIT_BLOCK)
+            ok &= fabs(edges[b] - fma((double)b, width, e0)) * per_bin <= 2.384185791015625e-07;
+        if (!ok)
+            edges_off = 1;
+    }
     double c[3];
     const int st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
     if (threadIdx.x == 0 && kasa_out) {
@@ -697,10 +845,13 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
     }
     ph.mark(1);
     int32_t it[4] = {0, 0, 0, 0};
+    double reach[2] = {0.0, 0.0};
+    bool have_reach = false;
     if (st != PCFIT_ST_SPARSE)
-        lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph);
+        have_reach = lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph, reach);
     __syncthreads();
-    residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin);
+    residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin, wthr, edges_off == 0,
+                   have_reach, reach);
     ph.mark(5);
     if (threadIdx.x == 0) {
         out[3 * s] = c[0];
@@ -821,7 +972,7 @@ int launch_fit_residual(const double *x, const double *y, const int64_t *offsets
                         const double *edges, int64_t *hist, double *rmm, int64_t *amm, hipStream_t st)
 {
     if (S == 0) return PCFIT_OK;
-    const size_t lds_hist = H > 0 ? (size_t)(H + 1) * 8 + (size_t)H * 4 : 0;
+    const size_t lds_hist = H > 0 ? (size_t)(H + 1) * 8 + (size_t)hist_copies(H) * hist_stride(H) * 4 : 0;
     int rc = PCFIT_OK;
     dispatch_shape(pick_shape(max_len), [&](auto t) {
         using T = decltype(t);

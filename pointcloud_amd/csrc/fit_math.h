@@ -79,8 +79,10 @@ struct LmParams {
 // Huber threshold delta, or not part of the slice at all (valid false) - all by selects.
 //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
 //   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones; low = smallest distance
-__device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low, double px, double py, double px0,
-                                                 double py0, double pr, double delta, double root_delta, bool valid)
+//   low / high = smallest / largest distance
+__device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low, double &high, double px, double py,
+                                                 double px0, double py0, double pr, double delta, double root_delta,
+                                                 bool valid)
 {
     const double dx = px - px0, dy = py - py0;
     const double d2 = fma(dx, dx, dy * dy);
@@ -119,6 +121,14 @@ __device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low,
     acc[8] = fma(j2, rw, acc[8]);
     acc[9] = fma(psi, iv, acc[9]);
     low = valid ? fmin(low, ri) : low;
+    high = valid ? fmax(high, ri) : high;
+}
+
+__device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low, double px, double py, double px0,
+                                                 double py0, double pr, double delta, double root_delta, bool valid)
+{
+    double high = 0.0;
+    lm_point_general(acc, low, high, px, py, px0, py0, pr, delta, root_delta, valid);
 }
 
 // The LM loop between two sweeps.  Sweeps deliver their totals (12 sums as above, then the smallest
@@ -128,6 +138,7 @@ struct LmState {
     double cx, cy, rad;         // current parameters
     double tx, ty, tr;          // what the next sweep evaluates: first the start itself
     double lam, prev, min_ri;
+    double max_ri;              // (fit.hip only: its sweeps deliver the largest distance at tot[13])
     double step[3];
     int32_t it, acc_steps, n_first, n_sweeps;
     int32_t cur;                // which totals area holds H, g at (cx, cy, rad); -1: none yet
@@ -141,7 +152,7 @@ __device__ __forceinline__ void lm_begin(LmState &st, const double par[3], const
     st.rad = st.tr = par[2];
     st.lam = prm.lam0;
     st.prev = __longlong_as_double(0x7ff0000000000000ll);
-    st.min_ri = 0.0;
+    st.min_ri = st.max_ri = 0.0;
     st.step[0] = st.step[1] = st.step[2] = 0.0;
     st.it = st.acc_steps = st.n_first = st.n_sweeps = 0;
     st.cur = -1;
@@ -188,6 +199,7 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
     if (adopt) {
         st.cur = into;
         st.min_ri = trial[12];
+        st.max_ri = trial[13];
     }
     if (st.done)
         return;

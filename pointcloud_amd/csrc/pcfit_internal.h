@@ -335,6 +335,59 @@ __device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, 
     __syncthreads();
 }
 
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v = fmax(v, __shfl_xor(v, m, WAVE));
+    return v;
+}
+
+// The same with two extremes: the smallest `low` at dst[K] and the largest `high` at dst[K + 1].
+// scratch: (K + 2) * 16 doubles.
+template <int K, int NW>
+__device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low, double high, double *scratch,
+                                                     double *dst)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    rs_steps<K, 32>(v, lane);
+    bool valid = true;
+    const int k = rs_index<K, 32>(lane, valid);
+    low = wave_min(low);
+    high = wave_max(high);
+    if (valid && (lane & rs_lowmask<K, 32>()) == 0)
+        scratch[k * 16 + wave] = v[0];
+    if (lane == 0) {
+        scratch[K * 16 + wave] = low;
+        scratch[(K + 1) * 16 + wave] = high;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double part[NW];
+#pragma unroll
+        for (int w = 0; w < NW; w++)
+            part[w] = scratch[threadIdx.x * 16 + w];
+        double s = part[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+            s += part[w];
+        dst[threadIdx.x] = s;
+    } else if (threadIdx.x == K) {
+        double s = scratch[K * 16];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+            s = fmin(s, scratch[K * 16 + w]);
+        dst[K] = s;
+    } else if (threadIdx.x == K + 1) {
+        double s = scratch[(K + 1) * 16];
+#pragma unroll
+        for (int w = 1; w < NW; w++)
+            s = fmax(s, scratch[(K + 1) * 16 + w]);
+        dst[K + 1] = s;
+    }
+    __syncthreads();
+}
+
 // (theta, r) as the reference forms them: theta = (atan2(dy,dx) + 2pi) mod 2pi
 __device__ __forceinline__ double wrap_angle(double dy, double dx)
 {

@@ -5,14 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pointcloud_amd import _ffi as F
 from pointcloud_amd.synth import make_slices
 
-S, n, H = int(os.environ.get("S", 10000)), int(os.environ.get("NP", 8192)), 256
+S, n, H = int(os.environ.get("S", 10000)), int(os.environ.get("NP", 8192)), int(os.environ.get("H", 256))
 dev = torch.device("cuda", 0)
 xh, yh, offh = make_slices(S, n, seed=1, sigma=0.05, jitter=0.02)
 t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-x, y, off, edges = t(xh), t(yh), t(offh), t(np.linspace(-0.5, 0.5, H + 1))
+x, y, off, edges = t(xh), t(yh), t(offh), t(np.linspace(-0.5, 0.5, max(H, 1) + 1))
 kasa = torch.empty(S, 3, dtype=torch.float64, device=dev); fit = torch.empty_like(kasa)
 iters = torch.empty(S, 4, dtype=torch.int32, device=dev); status = torch.empty(S, dtype=torch.int32, device=dev)
-hist = torch.empty(S, H, dtype=torch.int64, device=dev); rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
+hist = torch.empty(S, max(H, 1), dtype=torch.int64, device=dev); rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
 amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
 p = lambda a: C.c_void_p(a.data_ptr())
 if os.environ.get("PHASES"):
