@@ -877,6 +877,55 @@ static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_l
     return PCFIT_OK;
 }
 
+// More windows than one count / scatter pass takes (a long scan cut very finely): the windows go in runs of
+// BIN_MAX_SLICES consecutive ones, every run a count and a scatter pass of its own over the scan (a point outside
+// a run's z range finds no window there), the runs' outputs one after the other.  Same members, order and bytes
+// as one pass would give.
+static int bin_in_runs(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
+                       bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
+                       DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st)
+{
+    const int64_t W = BIN_MAX_SLICES, G = (S + W - 1) / W;
+    const BinSrc rows = rows_of(dxyz);
+    std::vector<DevBuf> ws((size_t)G), off((size_t)G);
+    std::vector<double> geom((size_t)G * 3);
+    std::vector<int64_t> hoff;
+    std::vector<int64_t> base((size_t)G + 1, 0);
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0);
+        PCFIT_TRY(bin_check_windows(z_lo + s0, z_hi + s0, Sg, &geom[(size_t)g * 3]));
+        PCFIT_TRY(ws[(size_t)g].alloc(bin_plan(n_points, Sg).bytes));
+        PCFIT_TRY(off[(size_t)g].alloc((size_t)(Sg + 1) * 8));
+        PCFIT_TRY(count_launch(rows, n_points, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, &geom[(size_t)g * 3],
+                               off[(size_t)g].as<int64_t>(), ws[(size_t)g].p, ws[(size_t)g].bytes, st));
+        hoff.resize((size_t)Sg + 1);
+        PCFIT_TRY(off[(size_t)g].download(hoff.data(), hoff.size() * 8, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+        for (int64_t j = 0; j < Sg; j++)
+            offsets[s0 + j] = base[(size_t)g] + hoff[(size_t)j];
+        base[(size_t)g + 1] = base[(size_t)g] + hoff[(size_t)Sg];
+    }
+    const int64_t total = base[(size_t)G];
+    offsets[S] = total;
+    if (capacity >= 0 && total > capacity)
+        return PCFIT_OK;
+    PCFIT_TRY(doff.upload(offsets, (size_t)(S + 1) * 8, st));
+    PCFIT_TRY(dx.alloc((size_t)total * 8));
+    PCFIT_TRY(dy.alloc((size_t)total * 8));
+    if (want_perm) PCFIT_TRY(dperm.alloc((size_t)total * 8));
+    for (int64_t g = 0; g < G; g++) {
+        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0);
+        if (base[(size_t)g + 1] == base[(size_t)g])
+            continue;
+        PCFIT_TRY(scatter_launch(rows, n_points, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg,
+                                 &geom[(size_t)g * 3], off[(size_t)g].as<int64_t>(),
+                                 dx.as<double>() + base[(size_t)g], dy.as<double>() + base[(size_t)g],
+                                 want_perm ? dperm.as<int64_t>() + base[(size_t)g] : nullptr, nullptr, nullptr,
+                                 ws[(size_t)g].p, ws[(size_t)g].bytes, st));
+    }
+    return PCFIT_OK;
+}
+
 // Bin the scan on the device: offsets to the host (and to doff), x, y (and perm) left in dx, dy (dperm).
 // With capacity >= 0 and more members than that, only the offsets are produced.
 int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
@@ -885,16 +934,16 @@ int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, cons
 {
     PCFIT_REQUIRE(n_points >= 0 && S >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     PCFIT_REQUIRE(z_lo && z_hi && offsets, "bin: null pointer");
-    if (S > BIN_MAX_SLICES) {
-        set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)S);
-        return PCFIT_ERR_UNSUPPORTED;
-    }
+    PCFIT_REQUIRE(S < (1ll << 31), "bin: too many windows");
     double geom[3];
     PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
     DevBuf dlo, dhi, dws;
     PCFIT_TRY(dlo.upload(z_lo, (size_t)S * 8, st));
     PCFIT_TRY(dhi.upload(z_hi, (size_t)S * 8, st));
     PCFIT_TRY(doff.alloc((size_t)(S + 1) * 8));
+    if (S > BIN_MAX_SLICES)
+        return bin_in_runs(dxyz, n_points, z_lo, z_hi, S, want_perm, capacity, offsets, doff, dx, dy, dperm, dlo, dhi,
+                           st);
     // (read at every call so that a test can switch between the two forms; negative = never)
     const char *env = getenv("PCFIT_BIN_TWO_LEVEL_MIN");
     const int64_t two_level_min = env ? atoll(env) : BIN_TWO_LEVEL_MIN;
@@ -1000,20 +1049,24 @@ PCFIT_API int pcfit_scan_window_counts(const pcfit_scan *scan, const double *z_l
     PCFIT_HIP(hipGetDevice(&dev));
     PCFIT_REQUIRE(dev == scan->device, "window_counts: the scan lives on device %d, the current device is %d",
                   scan->device, dev);
-    double geom[3];
-    PCFIT_TRY(bin_check_windows(z_lo, z_hi, n_slices, geom));
     hipStream_t st = nullptr;
     DevBuf dlo, dhi, doff, dws;
     PCFIT_TRY(dlo.upload(z_lo, (size_t)n_slices * 8, st));
     PCFIT_TRY(dhi.upload(z_hi, (size_t)n_slices * 8, st));
-    PCFIT_TRY(doff.alloc((size_t)(n_slices + 1) * 8));
-    PCFIT_TRY(dws.alloc(pcfit_bin_workspace_bytes(scan->n_points, n_slices)));
-    PCFIT_TRY(pcfit_bin_count_dev(scan->xyz.as<double>(), scan->n_points, dlo.as<double>(), dhi.as<double>(), n_slices,
-                                  geom, doff.as<int64_t>(), dws.p, dws.bytes, st));
-    std::vector<int64_t> off((size_t)n_slices + 1);
-    PCFIT_TRY(doff.download(off.data(), off.size() * 8, st));
-    PCFIT_HIP(hipStreamSynchronize(st));
-    for (int64_t s = 0; s < n_slices; s++)
-        counts[s] = off[(size_t)s + 1] - off[(size_t)s];
+    std::vector<int64_t> off;
+    for (int64_t s0 = 0; s0 < n_slices; s0 += BIN_MAX_SLICES) {          // (runs of windows, as bin_in_runs)
+        const int64_t Sg = std::min<int64_t>(BIN_MAX_SLICES, n_slices - s0);
+        double geom[3];
+        PCFIT_TRY(bin_check_windows(z_lo + s0, z_hi + s0, Sg, geom));
+        PCFIT_TRY(doff.alloc((size_t)(Sg + 1) * 8));
+        PCFIT_TRY(dws.alloc(pcfit_bin_workspace_bytes(scan->n_points, Sg)));
+        PCFIT_TRY(pcfit_bin_count_dev(scan->xyz.as<double>(), scan->n_points, dlo.as<double>() + s0,
+                                      dhi.as<double>() + s0, Sg, geom, doff.as<int64_t>(), dws.p, dws.bytes, st));
+        off.resize((size_t)Sg + 1);
+        PCFIT_TRY(doff.download(off.data(), off.size() * 8, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+        for (int64_t s = 0; s < Sg; s++)
+            counts[s0 + s] = off[(size_t)s + 1] - off[(size_t)s];
+    }
     return PCFIT_OK;
 }

@@ -172,6 +172,10 @@ PCFIT_API int pcfit_residuals_batch_dev(const double *x, const double *y, const 
     PCFIT_REQUIRE(x && y && offsets && cxcyr && rmax_rmin && argmax_argmin, "residuals: null pointer");
     PCFIT_REQUIRE(n_bins == 0 || (edges && hist), "residuals: histogram asked for without edges/hist");
     const size_t lds = n_bins > 0 ? (size_t)(n_bins + 1) * 8 + (size_t)n_bins * 4 : 0;
+    // more than 64 KB of dynamic LDS has to be granted explicitly (per device; idempotent)
+    if (lds > 48 * 1024)
+        PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&residuals_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(residuals_kernel, dim3((unsigned)n_slices), dim3(RES_BLOCK), lds, as_stream(stream), x, y,
                        offsets, cxcyr, theta, dr, radius, n_bins, edges, hist, rmax_rmin, argmax_argmin);
     PCFIT_LAUNCH_CHECK();
@@ -188,6 +192,9 @@ PCFIT_API int pcfit_angle_max_batch_dev(const double *x, const double *y, const 
         return PCFIT_OK;
     PCFIT_REQUIRE(x && y && offsets && cxcyr && sel, "angle_max: null pointer");
     const size_t lds = (size_t)bins * 12;
+    if (lds > 48 * 1024)
+        PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&angle_max_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(angle_max_kernel, dim3((unsigned)n_slices), dim3(RES_BLOCK), lds, as_stream(stream), x, y,
                        offsets, cxcyr, bins, sel);
     PCFIT_LAUNCH_CHECK();

@@ -269,6 +269,51 @@ def test_bin_slices_stable_and_exact():
     assert np.array_equal(x, q[perm, 0]) and np.array_equal(y, q[perm, 1])
 
 
+def test_more_windows_than_one_binning_pass_takes():
+    """A long scan cut very finely: 40 000 windows (runs of 16 384 inside the library) - members and order as the
+    CPU gives them, through bin_slices, the resident scan's window counts and the analyzer."""
+    from pointcloud_amd import Config, CylinderAnalyzer
+    pts = R.make_cylinder(400_000, 100, seed=19)                  # z in [0, 200]
+    lo = 0.005 * np.arange(40_000)
+    hi = lo + 0.005                                               # shared edges
+    pts[1000:1400, 2] = lo[::100]                                 # points on them, also across the runs' borders
+    pts[1400, 2], pts[1401, 2] = lo[16_384], lo[32_768]
+    off, x, y, perm = F.bin_slices(pts, lo, hi)
+    o_ref, p_ref = N.bin_slices(pts, lo, hi)
+    assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref)
+    assert np.array_equal(x, pts[perm, 0]) and np.array_equal(y, pts[perm, 1])
+    with F.DeviceScan(pts) as scan:
+        assert np.array_equal(scan.window_counts(lo, hi), np.diff(o_ref))
+        az = CylinderAnalyzer(Config(z_step=0.01, min_points_per_slice=25))
+        res = az.analyze_with_progress(scan)
+    zc = az.calculate_z_centers(pts)
+    assert len(zc) == 20_000 > 16_384
+    counts = np.array([np.count_nonzero(np.abs(pts[:, 2] - c) <= 0.005) for c in zc[::997]])
+    got = {r["z_center"]: r for r in res}
+    for c, k in zip(zc[::997], counts):
+        assert (c in got) == (k >= 25)
+        if c in got:
+            assert got[c]["n_points_slice"] == k
+
+
+def test_histograms_and_angular_bins_at_their_upper_bounds():
+    """8192 residual bins / 8192 angular bins (more than 64 KB of LDS per workgroup), 4096 bins in the fused
+    launch: against the CPU restatement."""
+    xy = R.make_slab(30_000, 93, outlier=0.02)[:, :2]
+    x, y, off = csr([xy, xy[:5000]])
+    fit, _ = F.kasa_batch(x, y, off)
+    r = F.residuals_batch(x, y, off, fit, bins=8192, lo=-0.4, hi=0.4)
+    sel = F.angle_max_batch(x, y, off, fit, bins=8192)
+    for s, pts in enumerate((xy, xy[:5000])):
+        o = N.residuals(pts, *fit[s], bins=8192, lo=-0.4, hi=0.4)
+        assert np.array_equal(o["hist"], r["hist"][s])
+        assert np.array_equal(N.angle_max(pts, fit[s][0], fit[s][1], 8192), sel[s])
+    a = _fused_dev(x[:10_000], y[:10_000], np.array([0, 6000, 10_000]), 4096, -0.4, 0.4)
+    for s, sl in enumerate((slice(0, 6000), slice(6000, 10_000))):
+        o = N.residuals(xy[sl], *a["fit"][s], bins=4096, lo=-0.4, hi=0.4)
+        assert np.array_equal(o["hist"], a["hist"][s])
+
+
 def test_degenerate_slices():
     same = np.tile([[1.5, -2.5]], (10, 1))
     line = np.stack([np.arange(12.0), 2 * np.arange(12.0)], 1)
@@ -509,6 +554,89 @@ def _fused_dev(x, y, off, H, lo, hi, want_resid=True):
     torch.cuda.synchronize()
     c = lambda a: a.cpu().numpy()
     return dict(kasa=c(ok_), fit=c(of_), iters=c(oi), status=c(os_), hist=c(oh), rmm=c(orm), amm=c(oam))
+
+
+def _oracle_resid(pts, fit, edges):
+    """The C restatement's residual statistics about `fit` with the given edges (any, not only linspace)."""
+    import ctypes as C
+    n, H = len(pts), len(edges) - 1
+    x, y = np.ascontiguousarray(pts[:, 0]), np.ascontiguousarray(pts[:, 1])
+    hist, rmm, amm = np.zeros(H, np.int64), np.zeros(2), np.zeros(2, np.int64)
+    N.lib().orc_residuals(x, y, n, fit[0], fit[1], fit[2], None, None, H, np.ascontiguousarray(edges), hist, rmm, amm)
+    return hist, rmm, amm
+
+
+def test_fused_residual_pass_where_the_quick_radius_cannot_decide():
+    """The fused launch takes bins and extremes from a quick radius and runs the exact code only where that cannot
+    decide.  Cases built to sit on those decisions: histogram ranges that begin / end exactly on a data value (a
+    point on the first edge, on the closed last edge, on inner edges), the largest and the smallest radius attained
+    twice (first index wins), a point on the centre, edges that are not uniformly spaced, a huge and a tiny bin
+    width, slices without any full group of points.  Everything against the C restatement at the kernel's own fit."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    gen = np.random.default_rng(2024)
+
+    def fused(pts, edges):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        p = lambda a: C.c_void_p(a.data_ptr())
+        n, H = len(pts), len(edges) - 1
+        dx, dy, doff, dedge = t(pts[:, 0]), t(pts[:, 1]), t(np.array([0, n], np.int64)), t(edges)
+        kas, fit = torch.empty(1, 3, dtype=torch.float64, device=dev), torch.empty(1, 3, dtype=torch.float64, device=dev)
+        it, st_ = torch.empty(1, 4, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
+        hist = torch.full((1, H), -5, dtype=torch.int64, device=dev)
+        rmm, amm = torch.empty(1, 2, dtype=torch.float64, device=dev), torch.empty(1, 2, dtype=torch.int64, device=dev)
+        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), 1, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kas),
+                                                      p(fit), p(it), p(st_), H, p(dedge), p(hist), p(rmm), p(amm),
+                                                      C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        torch.cuda.synchronize()
+        c = lambda a: a.cpu().numpy()
+        return c(fit)[0], c(hist)[0], c(rmm)[0], c(amm)[0]
+
+    def check(pts, edges, tag):
+        fit, hist, rmm, amm = fused(pts, edges)
+        h, r, a = _oracle_resid(pts, fit, edges)
+        assert np.array_equal(hist, h), tag
+        assert np.array_equal(rmm, r) and np.array_equal(amm, a), tag
+        return fit
+
+    for n in (8192, 7000, 4100, 2048, 1024, 1023, 300):
+        pts = R.make_slab(n, 500 + n, outlier=0.0)[:, :2]
+        H = 256
+        fit = check(pts, np.linspace(-0.5, 0.5, H + 1), (n, "plain"))
+        dr = N.residuals(pts, *fit)["dr"]
+        picks = gen.choice(n, 6, replace=False)
+        for k in picks:                                            # ranges that start / end on a data value
+            check(pts, np.linspace(dr[k], dr[k] + 0.3, H + 1), (n, "first edge on a point"))
+            check(pts, np.linspace(dr[k] - 0.3, dr[k], H + 1), (n, "last edge on a point"))
+            e = np.linspace(-0.5, 0.5, H + 1)
+            b = int(np.clip(np.searchsorted(e, dr[k]), 1, H - 1))
+            shift = dr[k] - e[b]
+            check(pts, e + shift, (n, "an inner edge next to a point"))
+        e = np.linspace(-0.5, 0.5, H + 1)
+        e[100] += 3e-4 * (e[1] - e[0])
+        check(pts, e, (n, "edges not uniform"))
+        check(pts, np.linspace(-1e9, 1e9, 9), (n, "huge bins"))
+        check(pts, np.linspace(-1e-9, 1e-9, 513), (n, "tiny bins"))
+        # extremes attained twice, and a point (nearly) on the centre
+        r = np.hypot(pts[:, 0] - fit[0], pts[:, 1] - fit[1])
+        twice = pts.copy()
+        i_hi, i_lo = int(np.argmax(r)), int(np.argmin(r))
+        j_hi, j_lo = (i_hi + n // 2) % n, (i_lo + n // 3) % n
+        if len({i_hi, i_lo, j_hi, j_lo}) == 4:
+            twice[j_hi], twice[j_lo] = twice[i_hi], twice[i_lo]
+            fit2, hist, rmm, amm = fused(twice, np.linspace(-0.5, 0.5, H + 1))
+            h, rr, a = _oracle_resid(twice, fit2, np.linspace(-0.5, 0.5, H + 1))
+            assert np.array_equal(hist, h) and np.array_equal(rmm, rr) and np.array_equal(amm, a)
+            r2 = np.hypot(twice[:, 0] - fit2[0], twice[:, 1] - fit2[1])
+            if np.argmax(r2) in (i_hi, j_hi):
+                assert amm[0] == min(i_hi, j_hi)
+    # a symmetric cloud with four points at the origin: the smallest radius is three orders below the rest
+    q = R.make_slab(1024, 77)[:, :2] - np.array([3.0, -2.0])
+    sym = np.concatenate([q, q * [-1, 1], q * [1, -1], q * [-1, -1]])
+    sym[5::1024] = 0.0                                            # a point and its three mirror images
+    fit = check(sym, np.linspace(-10.5, 0.5, 257), "points next to the centre")
+    assert abs(fit[0]) < 0.01 and abs(fit[1]) < 0.01          # (the Huber-weighted refinement drifts a little)
 
 
 def test_fit_on_ragged_slices_of_up_to_8192_points():
