@@ -117,7 +117,7 @@ def test_dropin_signatures_match_the_reference():
     assert np.array_equal(az.calculate_z_centers(pts), np.arange(2.5, 4.5 + 1e-9, 1.0))
 
 
-def test_text_loader_matches_the_reference_on_awkward_lines(tmp_path):
+def _text_loader_against_the_reference(tmp_path):
     """load_txt_points (native parser + literal rule for flagged lines) against the output of the
     reference's loader recorded in tests/golden/data_io.npz, for 1 thread and for several."""
     import os
@@ -140,7 +140,17 @@ def test_text_loader_matches_the_reference_on_awkward_lines(tmp_path):
         load_txt_points(str(tmp_path / "empty.txt"))
 
 
-def test_csv_writers_match_the_reference_bytes(tmp_path):
+def test_text_loader_matches_the_reference_on_awkward_lines(tmp_path):
+    _text_loader_against_the_reference(tmp_path)
+
+
+@pytest.mark.gpu
+def test_text_loader_matches_the_reference_on_the_gpu_box(tmp_path):
+    """The same check where the GPU tests run (the loader is host code; this pins it on that machine too)."""
+    _text_loader_against_the_reference(tmp_path)
+
+
+def _csv_writers_against_the_reference(tmp_path):
     """save_results writes what the reference wrote for the same results (recorded CSV bytes)."""
     import os
     import pandas as pd
@@ -155,6 +165,15 @@ def test_csv_writers_match_the_reference_bytes(tmp_path):
     save_results(results, frames, str(tmp_path))
     assert (tmp_path / "slice_results.csv").read_bytes() == g["results_csv"].tobytes()
     assert (tmp_path / "slice_points.csv").read_bytes() == g["points_csv"].tobytes()
+
+
+def test_csv_writers_match_the_reference_bytes(tmp_path):
+    _csv_writers_against_the_reference(tmp_path)
+
+
+@pytest.mark.gpu
+def test_csv_writers_match_the_reference_bytes_on_the_gpu_box(tmp_path):
+    _csv_writers_against_the_reference(tmp_path)
 
 
 def test_header_is_valid_c_and_links_against_the_library(tmp_path):

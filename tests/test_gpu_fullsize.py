@@ -1,0 +1,92 @@
+"""The large configurations at their full sizes (needs a GPU and a few GB of host memory): a 50 M-point scan
+(the unit of the 64-scan batch) through the analyzer and through the scan-batch driver, and a 100 M-point scan in
+2000 windows through binning, fits, angular-bin boundary and residual histograms.  Inputs follow the numpy recipe
+of the synthetic cylinder; a handful of windows of each run is replayed on the CPU restatements."""
+import numpy as np
+import pytest
+
+from oracle import native as N
+from oracle import ref_np as R
+from pointcloud_amd import _ffi as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+def _same_as_cpu(pts, got, zc):
+    want, _, warn = R.process_slice(pts, zc)
+    assert warn is None
+    assert got["z_center"] == zc
+    assert got["n_points_slice"] == want["n_points_slice"] and got["n_edge"] == want["n_edge"]
+    assert got["boundary_points"] == want["boundary_points"]
+    for key in ("cx", "cy", "R", "Rmax", "Rmin", "ovality_abs", "ovality_pct"):
+        assert abs(got[key] - want[key]) <= 1e-9 * max(1.0, abs(want[key])), key
+    for key in ("x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin"):
+        assert got[key] == want[key]
+    assert abs(got["k2_amp"] - want["k2_amp"]) < 1e-12
+
+
+def test_fifty_million_point_scans_alone_and_as_a_batch():
+    """One scan of 5e7 points in 1000 windows through DeviceScan + analyze_with_progress, four windows replayed on
+    the CPU; then three such scans (loaded on demand) through analyze_scans_sharded: the first equals the single
+    run dict for dict, two windows of each of the others are replayed."""
+    from pointcloud_amd import Config, CylinderAnalyzer, DeviceScan, sharding
+    n, S = 50_000_000, 1000
+    az = CylinderAnalyzer(Config())
+    pts = R.make_cylinder(n, S, seed=100, outlier_frac=0.0)
+    with DeviceScan(pts) as scan:
+        assert (scan.z_min, scan.z_max) == (0.0, 2.0 * S)
+        res = az.analyze_with_progress(scan)
+    zc = az.calculate_z_centers(pts)
+    assert len(zc) == S and [r["z_center"] for r in res] == list(zc)
+    for s in (0, 333, 778, 999):
+        _same_as_cpu(pts, res[s], zc[s])
+    kept = {}
+
+    def loader(k):
+        def load():
+            kept[k] = pts if k == 0 else R.make_cylinder(n, S, seed=100 + k, outlier_frac=0.0)
+            return kept[k]
+        return load
+    seen = []
+    batch = sharding.analyze_scans_sharded(az, [loader(k) for k in range(3)], progress_callback=seen.append)
+    assert seen == [33, 66, 100] and [len(b) for b in batch] == [S, S, S]
+    assert batch[0] == res
+    for k in (1, 2):
+        for s in (5, 600 + k):
+            _same_as_cpu(kept[k], batch[k][s], zc[s])
+
+
+def test_hundred_million_points_in_two_thousand_windows():
+    """1e8 points, 2000 windows of about 50 000 points, 10 % outliers: binning (two levels inside the library),
+    Kasa + LM, the angular-bin boundary (720 bins) and residual histograms (256 bins over +-10 sigma); four
+    windows replayed on the CPU; every point accounted for."""
+    n, S = 100_000_000, 2000
+    pts = R.make_cylinder(n, S, seed=3, outlier_frac=0.1)
+    z = pts[:, 2]
+    zc, lo, hi = R.slice_windows(0.0, S * 2.0, 2.0)
+    off, x, y, _ = F.bin_slices(pts, lo, hi, want_perm=False)
+    inside = np.count_nonzero((z >= lo[0]) & (z <= hi[-1]))
+    assert off[-1] == inside + np.count_nonzero(np.isin(z, lo[1:]))
+    kasa, st = F.kasa_batch(x, y, off)
+    fit, iters = F.lm_batch(x, y, off, kasa)
+    sel = F.angle_max_batch(x, y, off, fit, bins=720)
+    res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
+    assert np.all(st == 0) and res["hist"].sum() <= off[-1]
+    for s in (0, 611, 1370, 1999):
+        m = R.slice_members(z, lo[s], hi[s])
+        assert off[s + 1] - off[s] == m.size
+        assert np.array_equal(x[off[s]:off[s + 1]], pts[m, 0]) and np.array_equal(y[off[s]:off[s + 1]], pts[m, 1])
+        xy = pts[m, :2]
+        so, ko = N.kasa(xy[:, 0], xy[:, 1])
+        assert rel(kasa[s], ko) < 1e-11
+        lo_, _, _ = N.lm(xy[:, 0], xy[:, 1], ko)
+        assert rel(fit[s], lo_) < 1e-7                          # 10 % outliers: noise-limited stopping rule
+        assert np.array_equal(N.angle_max(xy, fit[s][0], fit[s][1], 720), sel[s])
+        o = N.residuals(xy, *fit[s], bins=256, lo=-0.5, hi=0.5, per_point=False)
+        assert np.array_equal(o["hist"], res["hist"][s])
+        assert (o["argmax"], o["argmin"]) == (res["argmax"][s], res["argmin"][s])
