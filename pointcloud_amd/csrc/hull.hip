@@ -65,6 +65,7 @@ __device__ unsigned long long g_hull_phase[8];
 #define HULL_MARK_INIT() do { } while (0)
 #endif
 constexpr int HULL_LDS_CAP = 8192;
+constexpr int HULL_BRUTE_MAX = 96;            // candidates of a chain from which on every one tests itself (chain_finish)
 constexpr int HULL_SMALL_CAP = 2048;          // LDS capacity (points) of the narrow launch
 constexpr int64_t HULL_NARROW_MIN_SLICES = 512;   // fewer slices than this do not fill the chip either way
 
@@ -178,6 +179,68 @@ __device__ __forceinline__ int chain_chunk(const double *px, const double *py, I
     return k;
 }
 
+// The end of a chain: once a round has left at most HULL_BRUTE_MAX candidates every one of them decides for
+// itself, all at once.  Candidate q stays exactly when it lies strictly to the right of the chord from A to B
+// (walking the chain: a left turn at q), A being the candidate before q from which the line to q turns least
+// to the left of all and B the one after q likewise - any other chord over q passes on the far side of that
+// one.  One thread per candidate walks all the others (the candidate looked at is the same for every thread:
+// LDS broadcasts).  The test is the chain's own exact orientation test, so the survivors are the chain's.  Rounds of chunks down to one thread's chunk, which this replaces, were a string of barriers and a
+// serial tail: about 40 us for the 200 points that the interior filter leaves of a long slice, against 10.
+template <class IdxT>
+__device__ int chain_finish(const double *px, const double *py, IdxT *list, int L, int *scratch)
+{
+    __shared__ double fx[HULL_BRUTE_MAX], fy[HULL_BRUTE_MAX];
+    const int q = threadIdx.x;
+    const bool have = q < L;
+    double qx = 0.0, qy = 0.0;
+    IdxT me = 0;
+    __syncthreads();                                    // (fx, fy may still be read by the previous chain's finish)
+    if (have) {
+        me = list[q];
+        qx = fx[q] = px[me];
+        qy = fy[q] = py[me];
+    }
+    __syncthreads();
+    // orient_sign with its floating-point filter inlined (the call is left for what the filter cannot tell)
+    auto turn = [&](double ax, double ay, double bx, double by, double cx, double cy) {
+        const double l = (bx - ax) * (cy - ay), r = (by - ay) * (cx - ax);
+        const double det = l - r;
+        const double bound = 3.3306690738754716e-16 * (fabs(l) + fabs(r));
+        if (det > bound) return 1;
+        if (det < -bound) return -1;
+        return orient_sign(ax, ay, bx, by, cx, cy);
+    };
+    int keep = 0;
+    if (have) {
+        keep = 1;
+        if (q > 0 && q < L - 1) {
+            // A: among the candidates before q; B: among those after q
+            double ax = fx[0], ay = fy[0], bx = fx[L - 1], by = fy[L - 1];
+            for (int c = 1; c < q; c++) {
+                const double cx = fx[c], cy = fy[c];
+                if (turn(ax, ay, qx, qy, cx, cy) < 0) {         // c right of A -> q
+                    ax = cx;
+                    ay = cy;
+                }
+            }
+            for (int c = q + 1; c < L - 1; c++) {
+                const double cx = fx[c], cy = fy[c];
+                if (turn(qx, qy, bx, by, cx, cy) < 0) {         // c right of q -> B
+                    bx = cx;
+                    by = cy;
+                }
+            }
+            keep = turn(ax, ay, qx, qy, bx, by) > 0 ? 1 : 0;
+        }
+    }
+    int total;
+    const int at = block_exscan(keep, scratch, &total);         // (its barriers end all reads of the list)
+    if (keep)
+        list[at] = me;
+    __syncthreads();
+    return total;
+}
+
 // Monotone chain over the candidates list[0..L) -> hull chain at list[0..return)
 template <class IdxT>
 __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, int64_t L, int64_t *pong,
@@ -186,10 +249,12 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
     constexpr int C0 = 16;
     int64_t c = C0;
     while (true) {
-        if (L <= c) {                                   // one thread finishes
+        if (L <= HULL_BRUTE_MAX)
+            return chain_finish<IdxT>(px, py, list, (int)L, scratch);
+        if (L <= c) {                                   // (all of them vertices, round after round:) one thread finishes
             __shared__ int last_k;
             if (threadIdx.x == 0)
-                last_k = chain_chunk(px, py, list, L, L > 0 ? L : 1);
+                last_k = chain_chunk(px, py, list, L, L);
             __syncthreads();
             const int k = last_k;
             __syncthreads();
@@ -444,7 +509,6 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
         py = wsy + off;
         list = reinterpret_cast<IdxT *>(wslist + off);
     }
-    int64_t *pong = hull_idx + off;
     const int tid = threadIdx.x;
     HULL_MARK_INIT();
     if (tid == 0) {
@@ -634,6 +698,7 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     }
 
     HULL_MARK(3);
+    int64_t *pong = hull_idx + off;
     // ---- hull: lower chain (left to right), then upper chain (right to left)
     for (int64_t i = tid; i < m; i += HULL_NT)
         list[i] = (IdxT)i;

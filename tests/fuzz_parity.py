@@ -128,7 +128,7 @@ def one_round(seed):
                 hv = uniq[N.hull(uniq)]
                 if not np.array_equal(got_u[uh["hull_idx"][o0:o0 + nh]], hv):
                     note(seed, s, "hull", tag)
-                if n <= 8192 and not np.array_equal(got_u, uniq):
+                if not np.array_equal(got_u, uniq):
                     note(seed, s, "unique", tag)
             elif len(uniq) >= 3 and N.has_2d_variation(uniq) != (uh["status"][s] == 0) and kinds[s] not in ("line",):
                 note(seed, s, "rank check", f"{tag} status {uh['status'][s]}")
@@ -185,7 +185,14 @@ def hybrid_round(seed):
             scale = np.abs(want).max() if kinds[s] == "far" else None
             err = float(np.max(np.abs(h["fit"][s] - want)) / scale) if scale else rel(h["fit"][s], want)
             if not err <= (1e-4 if kinds[s] == "arc" and abs(want[2]) > 100.0 else 1e-6):   # (near-line, as above)
-                note(seed, s, "hybrid fit", f"{tag} {err:.2e}")
+                # The reference's last accept / reject decisions can hang on the rounding of its cost sums (short
+                # arcs, heavy outliers): then the plain C loop leaves numpy's result by as much, and it is the C
+                # loop, operation for operation, that the kernels are held to.
+                inl = ref["candidates_xy"][ref["inlier_mask"]]
+                _, k0 = N.kasa(np.ascontiguousarray(inl[:, 0]), np.ascontiguousarray(inl[:, 1]))
+                c_fit, _, _ = N.lm(np.ascontiguousarray(inl[:, 0]), np.ascontiguousarray(inl[:, 1]), k0)
+                if not rel(h["fit"][s], c_fit) <= 1e-9:
+                    note(seed, s, "hybrid fit", f"{tag} {err:.2e} (C loop: {rel(h['fit'][s], c_fit):.2e})")
     return S, sum(sizes)
 
 
