@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--bins", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the timings of the other configurations")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the timings of the subsystems alone (a profile then holds the timed launches only)")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL) on GPUs; gloo only rehearses the launch")
     a = ap.parse_args()
 
@@ -316,7 +318,7 @@ def main():
         return e0.elapsed_time(e1) / reps
 
     side = []
-    if rank == 0:
+    if rank == 0 and not a.no_side:
         iters_side = torch.empty_like(iters)
         fit_side = torch.empty(S, 3, dtype=torch.float64, device=dev)
         fit_side.copy_(fit[(a.warmup + a.steps - 1) % RING] if a.steps + a.warmup > 0 else fit[0])
@@ -392,11 +394,12 @@ def main():
             "kernels": side,
         }
         # the pass the 50 %-of-HBM target is stated for: algebraic fit + residual statistics, one read of the slice
-        kr = side[2]
-        out["roofline_kasa_residual_pass"] = {
-            "kernel": "fit_residual_kernel<16,16,256> with max_iter = 0", "bound": "hbm", "achieved": kr["hbm_gbs"],
-            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kr["hbm_frac"], "avg_launch_ms": kr["ms"],
-            "algorithmic_bytes": alg_bytes}
+        if side:
+            kr = side[2]
+            out["roofline_kasa_residual_pass"] = {
+                "kernel": "fit_residual_kernel<16,16,256> with max_iter = 0", "bound": "hbm", "achieved": kr["hbm_gbs"],
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kr["hbm_frac"], "avg_launch_ms": kr["ms"],
+                "algorithmic_bytes": alg_bytes}
         if not a.no_extra:
             out["extra"] = extra_configs(L, dev, stream)
         if world == 1 and not a.no_cpu_baseline:

@@ -33,13 +33,15 @@ extern __shared__ __attribute__((aligned(16))) double lds_dyn[];
 // workgroup adds the clocks spent between marks to g_phase[k].
 #ifdef PCFIT_PHASE_CLOCK
 __device__ unsigned long long g_phase[16];
+// (one workgroup in 64 reports: ten thousand workgroups adding to the same few words would be what is measured)
 struct Phase {
     long long last;
-    __device__ __forceinline__ void init() { last = clock64(); }
+    __device__ __forceinline__ bool on() const { return threadIdx.x == 0 && (blockIdx.x & 63) == 0; }
+    __device__ __forceinline__ void init() { last = on() ? wall_clock64() : 0; }
     __device__ __forceinline__ void mark(int k)
     {
-        if (threadIdx.x == 0) {
-            const long long now = clock64();
+        if (on()) {
+            const long long now = wall_clock64();
             atomicAdd(&g_phase[k], (unsigned long long)(now - last));
             last = now;
         }
@@ -76,7 +78,27 @@ struct SliceView {
     const double *xs, *ys;
     int32_t n;
     double rx[PT_R > 0 ? PT_R : 1], ry[PT_R > 0 ? PT_R : 1];
-    double sum_x, sum_y;        // this thread's share of the coordinate sums, taken while loading (not STREAM)
+    // This thread's share of the power sums of u = x - x0, v = y - y0 about the slice's first point (x0, y0),
+    // taken while the slice is loaded (not STREAM): su sv suu svv suv suuu svvv suvv svuu.  The algebraic fit
+    // needs moments about the mean; these give them without a pass of their own and without waiting for the
+    // mean (kasa_slice), and the first point is as near the data as any shift known before the loads return.
+    double m9[9];
+    double x0, y0;
+
+    __device__ __forceinline__ void take(double vx, double vy, bool valid)
+    {
+        const double u = valid ? vx - x0 : 0.0, v = valid ? vy - y0 : 0.0;
+        const double uu = u * u, vv = v * v;
+        m9[0] += u;
+        m9[1] += v;
+        m9[2] += uu;
+        m9[3] += vv;
+        m9[4] = fma(u, v, m9[4]);
+        m9[5] = fma(uu, u, m9[5]);
+        m9[6] = fma(vv, v, m9[6]);
+        m9[7] = fma(u, vv, m9[7]);
+        m9[8] = fma(v, uu, m9[8]);
+    }
 
     __device__ __forceinline__ void load(const double *x, const double *y, int64_t off, int64_t count)
     {
@@ -90,9 +112,16 @@ struct SliceView {
         // Loads come first in a workgroup's life and the CU's other workgroup is usually in the middle of
         // its arithmetic: raise the priority of these waves so that their loads get issued at once.
         __builtin_amdgcn_s_setprio(3);
-        sum_x = sum_y = 0.0;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            m9[k] = 0.0;
+        x0 = n > 0 ? xs[0] : 0.0;           // (uniform addresses: scalar loads)
+        y0 = n > 0 ? ys[0] : 0.0;
+        // All loads of a thread are issued before anything looks at what they bring (the scheduling fence keeps
+        // the compiler from weaving the arithmetic in between, which left eight loads in flight per wave and a
+        // workgroup waiting four times as long for its 128 KB): the memory system then sees the whole slice at once.
         if (!STREAM && n == (PT_R + PT_L) * FIT_BLOCK) {
-            // a slice that fills the storage: nothing but loads, all in flight together
+            // a slice that fills the storage
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
                 rx[k] = xs[threadIdx.x + k * FIT_BLOCK];
@@ -104,21 +133,16 @@ struct SliceView {
                 tx[k] = xs[threadIdx.x + (PT_R + k) * FIT_BLOCK];
                 ty[k] = ys[threadIdx.x + (PT_R + k) * FIT_BLOCK];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PT_R; k++)
+                take(rx[k], ry[k], true);
 #pragma unroll
             for (int k = 0; k < PT_L; k++) {
                 const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
                 lds_dyn[2 * j] = tx[k];
                 lds_dyn[2 * j + 1] = ty[k];
-            }
-#pragma unroll
-            for (int k = 0; k < PT_R; k++) {
-                sum_x += rx[k];
-                sum_y += ry[k];
-            }
-#pragma unroll
-            for (int k = 0; k < PT_L; k++) {
-                sum_x += tx[k];
-                sum_y += ty[k];
+                take(tx[k], ty[k], true);
             }
         } else if (n > 0) {
             // every load is unconditional (a point past the end reads the slice's last one and is then
@@ -127,22 +151,32 @@ struct SliceView {
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
                 const int32_t i = threadIdx.x + k * FIT_BLOCK;
-                const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
-                rx[k] = i < n ? vx : 0.0;
-                ry[k] = i < n ? vy : 0.0;
-                sum_x += rx[k];
-                sum_y += ry[k];
+                rx[k] = xs[i < last ? i : last];
+                ry[k] = ys[i < last ? i : last];
             }
             // the LDS part travels through registers
+            double tx[PT_L > 0 ? PT_L : 1], ty[PT_L > 0 ? PT_L : 1];
 #pragma unroll
             for (int k = 0; k < PT_L; k++) {
                 const int32_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
-                const double vx = xs[i < last ? i : last], vy = ys[i < last ? i : last];
+                tx[k] = xs[i < last ? i : last];
+                ty[k] = ys[i < last ? i : last];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PT_R; k++) {
+                const int32_t i = threadIdx.x + k * FIT_BLOCK;
+                take(rx[k], ry[k], i < n);
+                rx[k] = i < n ? rx[k] : 0.0;
+                ry[k] = i < n ? ry[k] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < PT_L; k++) {
+                const int32_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
                 const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
-                lds_dyn[2 * j] = vx;
-                lds_dyn[2 * j + 1] = vy;
-                sum_x += i < n ? vx : 0.0;
-                sum_y += i < n ? vy : 0.0;
+                lds_dyn[2 * j] = tx[k];
+                lds_dyn[2 * j + 1] = ty[k];
+                take(tx[k], ty[k], i < n);
             }
         } else {
 #pragma unroll
@@ -328,36 +362,58 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     if (P.n < 3)
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
-    double s1[2] = {0.0, 0.0};
+    double m[7];   // suu svv suv suuu svvv suvv svuu, about the mean
+    double mx, my;
     if constexpr (View::STREAM) {
+        double s1[2] = {0.0, 0.0};
         each_point(P, [&](double px, double py, int32_t, bool valid) {
             s1[0] += valid ? px : 0.0;
             s1[1] += valid ? py : 0.0;
         });
-    } else {
-        s1[0] = P.sum_x;            // summed in the same order while the slice was loaded
-        s1[1] = P.sum_y;
-    }
-    double *tot = red.totals(0);
-    block_reduce_to_lds<2, false, NW>(s1, 0.0, red.scratch(), tot);
-    const double mx = tot[0] / n, my = tot[1] / n;
-    double m[7] = {0, 0, 0, 0, 0, 0, 0};   // suu svv suv suuu svvv suvv svuu
-    each_point(P, [&](double px, double py, int32_t, bool valid) {
-        const double u = valid ? px - mx : 0.0, v = valid ? py - my : 0.0;
-        const double uu = u * u, vv = v * v;
-        m[0] += uu;
-        m[1] += vv;
-        m[2] = fma(u, v, m[2]);
-        m[3] = fma(uu, u, m[3]);
-        m[4] = fma(vv, v, m[4]);
-        m[5] = fma(u, vv, m[5]);
-        m[6] = fma(v, uu, m[6]);
-    });
-    tot = red.totals(1);
-    block_reduce_to_lds<7, false, NW>(m, 0.0, red.scratch(), tot);
+        double *tot = red.totals(0);
+        block_reduce_to_lds<2, false, NW>(s1, 0.0, red.scratch(), tot);
+        mx = tot[0] / n;
+        my = tot[1] / n;
 #pragma unroll
-    for (int k = 0; k < 7; k++)
-        m[k] = tot[k];
+        for (int k = 0; k < 7; k++)
+            m[k] = 0.0;
+        each_point(P, [&](double px, double py, int32_t, bool valid) {
+            const double u = valid ? px - mx : 0.0, v = valid ? py - my : 0.0;
+            const double uu = u * u, vv = v * v;
+            m[0] += uu;
+            m[1] += vv;
+            m[2] = fma(u, v, m[2]);
+            m[3] = fma(uu, u, m[3]);
+            m[4] = fma(vv, v, m[4]);
+            m[5] = fma(u, vv, m[5]);
+            m[6] = fma(v, uu, m[6]);
+        });
+        tot = red.totals(1);
+        block_reduce_to_lds<7, false, NW>(m, 0.0, red.scratch(), tot);
+#pragma unroll
+        for (int k = 0; k < 7; k++)
+            m[k] = tot[k];
+    } else {
+        // the power sums about the slice's first point came with the loads: one reduction, then the
+        // moments about the mean by the binomial identities (a, b = the mean, seen from the first point)
+        double q[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            q[k] = P.m9[k];
+        double *tot = red.totals(1);
+        block_reduce_to_lds<9, false, NW>(q, 0.0, red.scratch(), tot);
+        const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
+        const double a = su / n, b = sv / n;
+        mx = P.x0 + a;
+        my = P.y0 + b;
+        m[0] = suu - a * su;
+        m[1] = svv - b * sv;
+        m[2] = suv - a * sv;
+        m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
+        m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
+        m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
+        m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
+    }
     return kasa_from_moments(m, mx, my, n, out);
 }
 

@@ -150,13 +150,7 @@ constexpr double TWO_PI = 6.283185307179586476925286766559;
 // ---------------------------------------------------------------- device side
 // Butterfly sum over the 64 lanes of a wave: every lane ends with the same
 // value, the order of additions is fixed (bitwise reproducible).
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v += __shfl_xor(v, m, WAVE);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v);       // (below, once the lane exchanges are declared)
 
 // Sum K values per thread over a whole workgroup (blockDim.x a multiple of 64,
 // at most 1024).  All threads receive the K totals.  scratch: K * 16 doubles
@@ -211,6 +205,99 @@ __device__ __forceinline__ void block_sum_to_lds(double (&v)[K], double *scratch
     __syncthreads();
 }
 
+// ---- lane exchanges without the LDS crossbar
+// __shfl_xor travels through ds_bpermute (two of them per double, some hundred cycles each, one after the other
+// along a butterfly).  Inside a row of 16 lanes the data-parallel-primitive moves do the same in a few cycles,
+// and gfx950 swaps rows of 16 and halves of 32 lanes between two registers in one instruction.
+//   dpp_mov<CTRL, BANKS>(old, src): lanes of the banks (groups of four lanes of a row) in BANKS receive src from the
+//   lane CTRL names, the others keep old.
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_SAME = 0xE4, DPP_ROW_SHL4 = 0x104, DPP_ROW_SHR4 = 0x114,
+              DPP_ROW_ROR8 = 0x128;
+
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_mov(double old, double src)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Rows of 16 (HALF = 16) or halves of 32 lanes (HALF = 32): the lanes whose HALF bit is set receive b of their
+// partner (lane ^ HALF) in a, the others receive a of their partner in b; what is not exchanged stays.
+template <int HALF>
+__device__ __forceinline__ void swap_halves(double &a, double &b)
+{
+    int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+    if constexpr (HALF == 32) {
+        const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+        alo = l[0]; blo = l[1]; ahi = h[0]; bhi = h[1];
+    }
+    a = __hiloint2double(ahi, alo);
+    b = __hiloint2double(bhi, blo);
+}
+
+// One step of a reduce-scatter over the lane bit M: lanes with the bit clear end with x (own) + x (partner's),
+// lanes with the bit set with y (own) + y (partner's).  Same sums, same order of operands, as
+//     keep = up ? y : x;  send = up ? x : y;  keep + __shfl_xor(send, M).
+template <int M>
+__device__ __forceinline__ double rs_pair(double x, double y, int lane)
+{
+    if constexpr (M >= 16) {
+        swap_halves<M>(x, y);           // clear: x own, y = partner's x; set: y own, x = partner's y
+        return x + y;
+    } else if constexpr (M == 8) {
+        const double keep = dpp_mov<DPP_SAME, 0x3>(y, x);                 // banks 0, 1 = lanes with the bit clear
+        double other = dpp_mov<DPP_ROW_ROR8, 0xC>(y, y);
+        other = dpp_mov<DPP_ROW_ROR8, 0x3>(other, x);
+        return keep + other;
+    } else if constexpr (M == 4) {
+        const double keep = dpp_mov<DPP_SAME, 0x5>(y, x);                 // banks 0, 2
+        double other = dpp_mov<DPP_ROW_SHL4, 0x5>(y, x);                  // from lane + 4
+        other = dpp_mov<DPP_ROW_SHR4, 0xA>(other, y);                     // from lane - 4
+        return keep + other;
+    } else {
+        const bool up = (lane & M) != 0;
+        const double keep = up ? y : x, send = up ? x : y;
+        return keep + dpp_mov<M == 2 ? DPP_QUAD_XOR2 : DPP_QUAD_XOR1, 0xf>(send, send);
+    }
+}
+
+// the value of lane ^ M (M a power of two below 64)
+template <int M>
+__device__ __forceinline__ double lane_xor(double v, int lane)
+{
+    if constexpr (M >= 16) {
+        double a = v, b = v;
+        swap_halves<M>(a, b);           // clear: b = partner's; set: a = partner's
+        return (lane & M) ? a : b;
+    } else if constexpr (M == 8) {
+        return dpp_mov<DPP_ROW_ROR8, 0xf>(v, v);
+    } else if constexpr (M == 4) {
+        const double t = dpp_mov<DPP_ROW_SHL4, 0x5>(v, v);
+        return dpp_mov<DPP_ROW_SHR4, 0xA>(t, v);
+    } else {
+        return dpp_mov<M == 2 ? DPP_QUAD_XOR2 : DPP_QUAD_XOR1, 0xf>(v, v);
+    }
+}
+
+// v + (value of lane ^ M), without the select of lane_xor for the wide steps
+template <int M>
+__device__ __forceinline__ double add_lane_xor(double v, int lane)
+{
+    if constexpr (M >= 16) {
+        double a = v, b = v;
+        swap_halves<M>(a, b);
+        return a + b;                   // own + partner's on either side
+    } else {
+        return v + lane_xor<M>(v, lane);
+    }
+}
+
 // Reduce-scatter butterfly over a wave: CNT values per lane go in; each exchange
 // halves the number of values a lane carries (a lane keeps one half and sends the
 // other to its partner), so summing K values over 64 lanes moves about K + 5
@@ -224,17 +311,14 @@ __device__ __forceinline__ void rs_steps(double (&v)[K], int lane)
     if constexpr (M >= 1) {
         if constexpr (CNT > 1) {
             constexpr int H = (CNT + 1) / 2;
-            const bool up = (lane & M) != 0;
 #pragma unroll
             for (int j = 0; j < H; j++) {
                 const double hi = (j + H < CNT) ? v[j + H] : 0.0;
-                const double send = up ? v[j] : hi;
-                const double keep = up ? hi : v[j];
-                v[j] = keep + __shfl_xor(send, M, WAVE);
+                v[j] = rs_pair<M>(v[j], hi, lane);
             }
             rs_steps<H, M / 2>(v, lane);
         } else {
-            v[0] += __shfl_xor(v[0], M, WAVE);
+            v[0] = add_lane_xor<M>(v[0], lane);
             rs_steps<1, M / 2>(v, lane);
         }
     }
@@ -287,12 +371,31 @@ __device__ __forceinline__ double max_abs_no_nan(double a, double b)
     return r;
 }
 
+template <int M, class OP>
+__device__ __forceinline__ double wave_fold(double v, int lane, OP op)
+{
+    if constexpr (M >= 1) {
+        if constexpr (M >= 16) {
+            double a = v, b = v;
+            swap_halves<M>(a, b);
+            v = op(a, b);               // own and partner's, in one order or the other
+        } else {
+            v = op(v, lane_xor<M>(v, lane));
+        }
+        return wave_fold<M / 2>(v, lane, op);
+    } else {
+        return v;
+    }
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    return wave_fold<32>(v, (int)(threadIdx.x & 63), [](double a, double b) { return a + b; });
+}
+
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fmin(v, __shfl_xor(v, m, WAVE));
-    return v;
+    return wave_fold<32>(v, (int)(threadIdx.x & 63), [](double a, double b) { return fmin(a, b); });
 }
 
 // Sum K values per thread over a workgroup of NW waves and, when WITH_MIN, take
@@ -337,10 +440,7 @@ __device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, 
 
 __device__ __forceinline__ double wave_max(double v)
 {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1)
-        v = fmax(v, __shfl_xor(v, m, WAVE));
-    return v;
+    return wave_fold<32>(v, (int)(threadIdx.x & 63), [](double a, double b) { return fmax(a, b); });
 }
 
 // The same with two extremes: the smallest `low` at dst[K] and the largest `high` at dst[K + 1].

@@ -48,6 +48,8 @@ if os.environ.get("PHASES"):
     L2.pcfit_debug_phase_clocks(out, 0)
     names = ["load", "kasa", "sweep points (+solve)", "sweep reduce", "lm end", "residual"]
     tot = sum(out[:6])
+    sampled = (S + 63) // 64                       # one workgroup in 64 reports; wall_clock64 ticks at 100 MHz
     for k, nm in enumerate(names):
-        print(f"   phase {nm:14s} {out[k]/S:10.0f} clk/slice  {100*out[k]/max(tot,1):5.1f} %")
+        print(f"   phase {nm:22s} {out[k]/sampled/100:8.2f} us/slice  {100*out[k]/max(tot,1):5.1f} %")
+    print(f"   sum {tot/sampled/100:8.2f} us per slice and workgroup")
 print("iters", iters[:2].tolist())
