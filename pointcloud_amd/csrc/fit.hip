@@ -652,6 +652,22 @@ __device__ __forceinline__ Extreme2 better_min(Extreme2 a, Extreme2 b)
     return (b.r < a.r || (b.r == a.r && b.i < a.i)) ? b : a;
 }
 
+// butterfly over the wave: every lane ends with the wave's (largest radius, first index) and (smallest, first index)
+template <int M>
+__device__ __forceinline__ void fold_extremes(Extreme2 &mx, Extreme2 &mn, int lane)
+{
+    if constexpr (M >= 1) {
+        Extreme2 o;
+        o.r = lane_xor<M>(mx.r, lane);
+        o.i = lane_xor_i32<M>(mx.i, lane);
+        mx = better_max(mx, o);
+        o.r = lane_xor<M>(mn.r, lane);
+        o.i = lane_xor_i32<M>(mn.i, lane);
+        mn = better_min(mn, o);
+        fold_extremes<M / 2>(mx, mn, lane);
+    }
+}
+
 // Number of copies of the LDS histogram (lanes spread their updates over them by lane number, which
 // cuts the serialisation of lanes that hit one counter) and the distance between copies, in counters
 // (the extra 8 put the copies on different banks).
@@ -818,16 +834,7 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, false); });
     }
     P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, true); });
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        Extreme2 o;
-        o.r = __shfl_xor(mx.r, m, WAVE);
-        o.i = __shfl_xor(mx.i, m, WAVE);
-        mx = better_max(mx, o);
-        o.r = __shfl_xor(mn.r, m, WAVE);
-        o.i = __shfl_xor(mn.i, m, WAVE);
-        mn = better_min(mn, o);
-    }
+    fold_extremes<32>(mx, mn, lane);
     if (lane == 0) {
         wmax[wave] = mx;
         wmin[wave] = mn;

@@ -285,6 +285,31 @@ __device__ __forceinline__ double lane_xor(double v, int lane)
     }
 }
 
+template <int CTRL, int BANKS>
+__device__ __forceinline__ int dpp_mov_i32(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, 0xf, BANKS, false);
+}
+
+template <int M>
+__device__ __forceinline__ int lane_xor_i32(int v, int lane)
+{
+    if constexpr (M == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & M) ? r[0] : r[1];
+    } else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & M) ? r[0] : r[1];
+    } else if constexpr (M == 8) {
+        return dpp_mov_i32<DPP_ROW_ROR8, 0xf>(v, v);
+    } else if constexpr (M == 4) {
+        const int t = dpp_mov_i32<DPP_ROW_SHL4, 0x5>(v, v);
+        return dpp_mov_i32<DPP_ROW_SHR4, 0xA>(t, v);
+    } else {
+        return dpp_mov_i32<M == 2 ? DPP_QUAD_XOR2 : DPP_QUAD_XOR1, 0xf>(v, v);
+    }
+}
+
 // v + (value of lane ^ M), without the select of lane_xor for the wide steps
 template <int M>
 __device__ __forceinline__ double add_lane_xor(double v, int lane)
