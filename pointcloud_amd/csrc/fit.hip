@@ -340,9 +340,9 @@ __device__ __forceinline__ void each_point(const View &P, F &&f)
 }
 
 // Static LDS of a fit kernel, in doubles: two scratch areas for the workgroup
-// reductions (14 values x 16 waves each, used alternately) and two areas for
-// totals (12 sums, the smallest and the largest distance).
-constexpr int RED_SCR = 14 * 16, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 32;
+// reductions (17 values x 16 waves each, used alternately) and two areas for
+// totals (12 sums, the smallest and the largest distance, three model sums).
+constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 2 * RED_AREA;
 
 // Where the next reduction of a workgroup puts its partial sums.  Alternating
 // between two scratch areas (and never writing totals that may still be read)
@@ -351,7 +351,7 @@ struct RedCtx {
     double *lds;
     int count;
     __device__ __forceinline__ double *scratch() { return lds + (count++ & 1) * RED_SCR; }
-    __device__ __forceinline__ double *totals(int which) { return lds + RED_TOT + 16 * which; }
+    __device__ __forceinline__ double *totals(int which) { return lds + RED_TOT + RED_AREA * which; }
 };
 
 // circle_fitting.py:35-54.  Uniform result in every thread.
@@ -446,8 +446,10 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     // Huber-weighted problem, the curvature sum and the Huber cost, all from the same distances.
     //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
     //   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones
-    // The totals of a sweep stay in LDS (tot: 12 sums, then the smallest and the largest distance): they are the
-    // same for every thread, and keeping two sets of them in registers would cost 48 VGPRs per lane.
+    //   acc[12..14] sums of q j0^2, q j0 j1, q (q = residual / distance): what lm_model_step_is_last needs
+    // The totals of a sweep stay in LDS (tot: 12 sums, the smallest and the largest distance, the three model
+    // sums): they are the same for every thread, and keeping two sets of them in registers would cost 48 VGPRs
+    // per lane.
     //
     // Two forms of the pass.  The short one takes every point for a regular one: at a distance
     // above zero, within the Huber threshold, inside the slice; no branch, no select, and it notes
@@ -458,7 +460,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     bool general = false;
     auto sweep = [&](double px0, double py0, double pr, double *tot) {
         constexpr int U = View::GROUP;
-        double acc[12];
+        double acc[15];
         double low, high;
         auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
 #pragma unroll
@@ -469,7 +471,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
         auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, true); };
         if (!general) {
 #pragma unroll
-            for (int k = 0; k < 12; k++)
+            for (int k = 0; k < 15; k++)
                 acc[k] = 0.0;
             low = inf;
             high = -inf;
@@ -494,6 +496,10 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     acc[7] = fma(j1, r, acc[7]);
                     acc[8] = acc[8] - r;
                     acc[9] = fma(fabs(r), iv, acc[9]);
+                    const double q = r * iv, t0 = j0 * q;
+                    acc[12] = fma(t0, j0, acc[12]);
+                    acc[13] = fma(t0, j1, acc[13]);
+                    acc[14] = acc[14] + q;
                     low = min_no_nan(low, ri);
                 }
             });
@@ -507,21 +513,21 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);
-            block_reduce_to_lds2<12, NW>(acc, low, high, red.scratch(), tot);
+            block_reduce_to_lds2<15, NW, 12>(acc, low, high, red.scratch(), tot);
             ph.mark(3);
             if (tot[12] != -inf)
                 return;
             general = true;             // (every thread has read tot[12] before the barrier inside the next reduction)
         }
 #pragma unroll
-        for (int k = 0; k < 12; k++)
+        for (int k = 0; k < 15; k++)
             acc[k] = 0.0;
         low = inf;
         high = -inf;
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false); });
         P.ragged_group(ragged);
         ph.mark(2);
-        block_reduce_to_lds2<12, NW>(acc, low, high, red.scratch(), tot);
+        block_reduce_to_lds2<15, NW, 12>(acc, low, high, red.scratch(), tot);
         ph.mark(3);
     };
 
@@ -531,12 +537,12 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     while (!st.done) {
         const int into = lm_into(st);
         sweep(st.tx, st.ty, st.tr, red.totals(into));
-        lm_step(st, prm, red.totals(0), into);
+        lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
     }
     lm_finish(st, par, iters);
     ph.mark(4);
-    // smallest and largest distance (sqrt + 1e-16) of the slice's points from the returned centre: known when a
-    // sweep ran at exactly these parameters
+    // bounds of the smallest (from above) and the largest (from below) distance (sqrt + 1e-16) of the slice's points
+    // from the returned centre: known when a sweep ran at these parameters or one modelled step before them
     reach[0] = st.min_ri;
     reach[1] = st.max_ri;
     return st.cur >= 0;

@@ -78,9 +78,12 @@ struct LmParams {
 // One point's terms of a sweep at parameters (px0, py0, pr), any point: distance zero, beyond the
 // Huber threshold delta, or not part of the slice at all (valid false) - all by selects.
 //   acc[0..5] H00 H01 H02 H11 H12 H22, acc[6..8] g, acc[9] sum |psi|/r,
-//   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones; low = smallest distance
+//   acc[10] sum of squares of the small residuals, acc[11] linear part of the large ones;
+//   with 15 accumulators also acc[12..14]: sums of q j0^2, q j0 j1 and q, q = residual / distance (the part of the
+//   cost's second derivative that H leaves out; taken as if no point were beyond the threshold)
 //   low / high = smallest / largest distance
-__device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low, double &high, double px, double py,
+template <int NA>
+__device__ __forceinline__ void lm_point_general(double (&acc)[NA], double &low, double &high, double px, double py,
                                                  double px0, double py0, double pr, double delta, double root_delta,
                                                  bool valid)
 {
@@ -120,6 +123,13 @@ __device__ __forceinline__ void lm_point_general(double (&acc)[12], double &low,
     acc[7] = fma(j1, rw, acc[7]);
     acc[8] = fma(j2, rw, acc[8]);
     acc[9] = fma(psi, iv, acc[9]);
+    if constexpr (NA >= 15) {
+        const double q = valid ? res * iv : 0.0;
+        const double t0 = (valid ? -dx * iv : 0.0) * q;
+        acc[12] = fma(t0, -dx * iv, acc[12]);
+        acc[13] = fma(t0, -dy * iv, acc[13]);
+        acc[14] += q;
+    }
     low = valid ? fmin(low, ri) : low;
     high = valid ? fmax(high, ri) : high;
 }
@@ -143,6 +153,8 @@ struct LmState {
     int32_t it, acc_steps, n_first, n_sweeps;
     int32_t cur;                // which totals area holds H, g at (cx, cy, rad); -1: none yet
     bool first, done;
+    bool regular;               // (fit.hip only) the sweep at (cx, cy, rad) found every point at a distance above
+                                // zero and within the Huber threshold, and left the three model sums
 };
 
 __device__ __forceinline__ void lm_begin(LmState &st, const double par[3], const LmParams &prm)
@@ -156,17 +168,89 @@ __device__ __forceinline__ void lm_begin(LmState &st, const double par[3], const
     st.step[0] = st.step[1] = st.step[2] = 0.0;
     st.it = st.acc_steps = st.n_first = st.n_sweeps = 0;
     st.cur = -1;
+    st.regular = false;
     st.first = true;
     st.done = prm.max_iter <= 0;
 }
 
 __device__ __forceinline__ int lm_into(const LmState &st) { return st.cur == 0 ? 1 : 0; }
 
-// after the sweep at (tx, ty, tr) has left its totals in area `into`
-__device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const double *tot2, int into)
+// Whether the candidate p + d (d = st.step, solved from H, g at the current parameters p in hg) can be taken as
+// the loop's result without a sweep: the candidate is accepted, and every candidate after it is rejected.
+// Needs hg from a sweep that found every point regular (distance above zero, residual within the Huber
+// threshold) and that left, at hg[14..16], the sums of q j0^2, q j0 j1 and q (q = residual / distance).
+//
+// With all points regular the cost is F = 1/2 sum r_i^2, three times differentiable, with
+//    grad F = g,   hess F = H + B,   B = sum q_i (I - u_i u_i^T) on the centre block (u_i the unit vector to the point),
+// and a third derivative of at most L3 = sum (3 sqrt2 / rho_i + 3 |r_i| / rho_i^2) in norm.  So over the step d
+//    F(p + d) <= F(p) + g.d + d.(H + B) d / 2 + L3 |d|^3 / 6                    (i)
+//    |g(p + d) - (g + (H + B) d)| <= L3 |d|^2 / 2                                (ii)
+// (i) below F(p) - tol_cost (less an allowance for the rounding of the two costs the loop would compare) means
+// the loop accepts p + d.  At p + d every later candidate s = -(H' + mu D')^-1 g' has g'.s >= -g'.H'^-1 g' and
+// |s| <= |g'| / lmin(H'); H' differs from H by at most dH in norm, so with (ii), the lower bound
+//    F(p + d + s) >= F(p + d) + g'.s - |s_c|^2 sum |r_i| / rho_i
+// (convexity, as in lm_step) shows that none of them gains a quarter of tol_cost: all are rejected.
+// `slack`: how far the centre moves (the distances at p + d lie within that of those at p).
+__device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const LmParams &prm, const double *hg,
+                                                      double &slack)
+{
+    const double d0 = st.step[0], d1 = st.step[1], d2 = st.step[2];
+    const double H00 = hg[0], H01 = hg[1], H02 = hg[2], H11 = hg[3], H12 = hg[4], H22 = hg[5];
+    const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
+    const double n = H22, lo = hg[12], hi = hg[13], R = st.rad, F = st.prev;
+    const double dc2 = d0 * d0 + d1 * d1, dc = sqrt(dc2), move = dc + fabs(d2);
+    const double amax = fmax(hi - R, R - lo);
+    // all points stay regular over this step and another no longer than it; distances stay above rho
+    const double rho = lo - 2.0 * dc;
+    if (!(amax + 3.0 * move <= prm.delta && 16.0 * dc <= lo && R + d2 > 1e-12 && n >= 3.0 && F >= 0.0))
+        return false;
+    const double B00 = hg[16] - hg[14], B01 = -hg[15], B11 = hg[14];
+    const double Hd0 = H00 * d0 + H01 * d1 + H02 * d2, Hd1 = H01 * d0 + H11 * d1 + H12 * d2,
+                 Hd2 = H02 * d0 + H12 * d1 + H22 * d2;
+    const double Bd0 = B00 * d0 + B01 * d1, Bd1 = B01 * d0 + B11 * d1;
+    const double s1 = sqrt(2.0 * n * F) + 3.0 * n * move;       // sum |r_i| anywhere near (Cauchy-Schwarz at p)
+    const double L3 = (4.25 * n + 3.0 * s1 / rho) / rho;
+    const double dn2 = dc2 + d2 * d2, dn = sqrt(dn2);
+    const double Ef = L3 * dn2 * dn * (1.0 / 6.0), Eg = 0.5 * L3 * dn2;
+    const double dF = (g0 * d0 + g1 * d1 + g2 * d2) + 0.5 * (d0 * Hd0 + d1 * Hd1 + d2 * Hd2) +
+                      0.5 * (d0 * Bd0 + d1 * Bd1) + Ef;
+    if (!(dF < -(prm.tol_cost + 2e-15 * n * F)))
+        return false;
+    // the gradient at p + d, to within Eg
+    const double gh[3] = {g0 + Hd0 + Bd0, g1 + Hd1 + Bd1, g2 + Hd2};
+    double A[3][3] = {{H00, H01, H02}, {H01, H11, H12}, {H02, H12, H22}};
+    double b[3] = {gh[0], gh[1], gh[2]}, y[3];
+    if (!solve3x3(A, b, y))
+        return false;
+    const double a = gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2];                    // gh.H^-1 gh
+    const double yn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    const double gn = sqrt(gh[0] * gh[0] + gh[1] * gh[1] + gh[2] * gh[2]);
+    // the smallest eigenvalue of H from below: the other two have a product of at most (trace / 2)^2
+    const double det = H00 * (H11 * H22 - H12 * H12) - H01 * (H01 * H22 - H12 * H02) + H02 * (H01 * H12 - H11 * H02);
+    const double ht = 0.5 * (H00 + H11 + H22);
+    const double lmin = det / (ht * ht);
+    const double dH = 12.0 * n * dc / rho;           // each j j^T moves by at most 2 sqrt2 * 2 (2 dc) / rho
+    if (!(a >= 0.0 && lmin > 2.0 * dH))
+        return false;
+    const double lm2 = lmin - dH, kap = 1.0 + dH / lm2;
+    const double sn = (gn + Eg) / lm2;                // no later step is longer
+    const double val = kap * (a + 2.0 * yn * Eg + Eg * Eg / lmin) + sn * sn * (s1 / rho);
+    if (!(val < 0.25 * prm.tol_cost && sn <= dc && 2.0 * sn <= rho))
+        return false;
+    slack = dc;
+    return true;
+}
+
+// after the sweep at (tx, ty, tr) has left its totals in area `into`.  AREA: doubles per totals area.  MODEL:
+// the totals carry the model sums (`regular` says whether the sweep found every point regular), and a last
+// accepted step is taken without its sweep where lm_model_step_is_last allows; min_ri / max_ri are then bounds
+// (min_ri at least the smallest distance, max_ri at most the largest).
+template <int AREA = 16, bool MODEL = false>
+__device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const double *tot2, int into,
+                                        bool regular = false)
 {
     const double inf = __longlong_as_double(0x7ff0000000000000ll);
-    const double *trial = tot2 + 16 * into;
+    const double *trial = tot2 + AREA * into;
     bool adopt;
     if (st.first) {
         // H and g at the start; its cost is not used (the reference starts from cost_prev = inf)
@@ -200,11 +284,12 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
         st.cur = into;
         st.min_ri = trial[12];
         st.max_ri = trial[13];
+        st.regular = regular;
     }
     if (st.done)
         return;
     // next candidate from the current H, g (a singular damped system costs an iteration, as in the reference)
-    const double *hg = tot2 + 16 * st.cur;
+    const double *hg = tot2 + AREA * st.cur;
     bool have = false;
     while (st.it < prm.max_iter) {
         const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
@@ -226,6 +311,20 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
             if (gd + hg[9] * dc2 < 0.25 * prm.tol_cost && 4.0 * dc2 <= st.min_ri * st.min_ri) {
                 st.it = prm.max_iter;           // nothing from here on can be accepted
                 break;
+            }
+            if constexpr (MODEL) {
+                double slack;
+                if (st.regular && lm_model_step_is_last(st, prm, hg, slack)) {
+                    st.cx = st.cx + st.step[0];
+                    st.cy = st.cy + st.step[1];
+                    st.rad = st.rad + st.step[2];
+                    st.acc_steps++;
+                    st.min_ri += slack * (1.0 + 1e-9);
+                    st.max_ri -= slack * (1.0 + 1e-9);
+                    st.regular = false;
+                    st.it = prm.max_iter;
+                    break;
+                }
             }
         }
         st.tx = st.cx + st.step[0];

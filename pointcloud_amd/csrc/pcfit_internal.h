@@ -468,9 +468,9 @@ __device__ __forceinline__ double wave_max(double v)
     return wave_fold<32>(v, (int)(threadIdx.x & 63), [](double a, double b) { return fmax(a, b); });
 }
 
-// The same with two extremes: the smallest `low` at dst[K] and the largest `high` at dst[K + 1].
-// scratch: (K + 2) * 16 doubles.
-template <int K, int NW>
+// The same with two extremes: the smallest `low` at dst[AT] and the largest `high` at dst[AT + 1]; the sums
+// from the AT-th on follow them (sum k at dst[k + 2]).  scratch: (K + 2) * 16 doubles.
+template <int K, int NW, int AT = K>
 __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low, double high, double *scratch,
                                                      double *dst)
 {
@@ -496,19 +496,19 @@ __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low,
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s += part[w];
-        dst[threadIdx.x] = s;
+        dst[threadIdx.x < AT ? threadIdx.x : threadIdx.x + 2] = s;
     } else if (threadIdx.x == K) {
         double s = scratch[K * 16];
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s = fmin(s, scratch[K * 16 + w]);
-        dst[K] = s;
+        dst[AT] = s;
     } else if (threadIdx.x == K + 1) {
         double s = scratch[(K + 1) * 16];
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s = fmax(s, scratch[(K + 1) * 16 + w]);
-        dst[K + 1] = s;
+        dst[AT + 1] = s;
     }
     __syncthreads();
 }

@@ -1213,3 +1213,36 @@ def test_analyze_file_writes_the_reference_formats(tmp_path, monkeypatch, capsys
     want = pd.concat(frames, ignore_index=True).sort_values(["z_center", "theta"]).reset_index(drop=True)
     want_bytes = want.to_csv(index=False, float_format="%.6f").encode()
     assert (tmp_path / "slice_points.csv").read_bytes() == want_bytes
+
+
+def test_last_accepted_step_taken_without_its_sweep():
+    """Where the cost model proves that a candidate is accepted and everything after it rejected, the kernel takes
+    the candidate without sweeping over the points again.  Slices of many sizes, radii, noise levels and arcs, from
+    the Kasa start and from shifted starts: parameters, iteration and accepted-step counts of the literal loop."""
+    gen = np.random.default_rng(2024)
+    sets, inits = [], []
+    for i in range(240):
+        n = int(gen.choice([40, 200, 1000, 4096, 8192, 5000]))
+        rad = float(gen.choice([0.5, 3.0, 10.0, 50.0]))
+        sig = min(0.1, rad * float(gen.choice([1e-4, 2e-3, 5e-3, 2e-2])))      # within the Huber threshold of 1
+        arc = float(gen.choice([2 * np.pi, 2 * np.pi, np.pi, 0.6 * np.pi]))
+        th = gen.uniform(0.0, arc, n) + gen.uniform(0, 6.28)
+        rr = rad + gen.normal(0.0, sig, n)
+        c = gen.normal(0.0, 5.0, 2)
+        xy = np.stack([c[0] + rr * np.cos(th), c[1] + rr * np.sin(th)], 1)
+        sets.append(xy)
+        _, k = N.kasa(xy[:, 0], xy[:, 1])
+        if i % 3 == 2:
+            k = k + np.array([0.02 * rad, -0.01 * rad, 0.03 * rad])
+        inits.append(k)
+    x, y, off = csr(sets)
+    inits = np.array(inits)
+    fit, iters = F.lm_batch(x, y, off, inits)
+    modelled = iters[:, 1] > iters[:, 3]           # an accepted step more than candidates swept
+    assert modelled.mean() > 0.3
+    same_counts = 0
+    for s, xy in enumerate(sets):
+        want, it, acc = N.lm(xy[:, 0], xy[:, 1], inits[s])
+        assert rel(fit[s], want) < 1e-9, (s, modelled[s], fit[s], want)
+        same_counts += (iters[s, 0], iters[s, 1]) == (it, acc)
+    assert same_counts >= 0.97 * len(sets)

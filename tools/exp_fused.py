@@ -38,12 +38,13 @@ for mi in (100,):
     timeit(f"fit max_iter={mi}", lambda: F.check(L.pcfit_fit_batch_dev(p(x), p(y), p(off), S, n, 1.0, mi, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), st)))
     print("   sweeps", iters[0].tolist())
 timeit("kasa only", lambda: F.check(L.pcfit_kasa_batch_dev(p(x), p(y), p(off), S, n, p(kasa), p(status), st)))
+timeit("kasa+residuals fused", lambda: F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 0, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st)))
 timeit("fit+residuals fused", lambda: F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st)))
 if os.environ.get("PHASES"):
     out = (C.c_int64 * 16)()
     L2 = C.CDLL(F.SO_PATH)
     L2.pcfit_debug_phase_clocks(out, 1)
-    F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st))
+    F.check(L.pcfit_fit_residuals_batch_dev(p(x), p(y), p(off), S, n, 1.0, int(os.environ.get("MI", 100)), 1e-2, 1e-10, 1e-12, p(kasa), p(fit), p(iters), p(status), H, p(edges), p(hist), p(rmm), p(amm), st))
     torch.cuda.synchronize()
     L2.pcfit_debug_phase_clocks(out, 0)
     names = ["load", "kasa", "sweep points (+solve)", "sweep reduce", "lm end", "residual"]
