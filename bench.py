@@ -116,7 +116,8 @@ def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600, threads=1):
 
 def extra_configs(L, dev, stream):
     """Timings of the other configurations, outside the timed region (events on the kernels' stream):
-    seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice."""
+    seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice; binning of
+    100 M points in random z order into 2000 windows (both steps of the two-level form, nothing read back)."""
     out = {}
 
     def timed(fn, reps):
@@ -154,6 +155,36 @@ def extra_configs(L, dev, stream):
         "tflops_at_7_flop": evals * 7 / (ms * 1e-3) / 1e12,
         "valu_fp64_frac": evals * 7 / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
         "min_score": int(score.min().item()), "all_ok": bool((st == 0).all().item())}
+    del x, y, off, tab, tof, model, score, best, st, mask, ws
+    torch.cuda.empty_cache()
+
+    n, S = 100_000_000, 2000
+    xyz = torch.rand(n, 3, generator=g, device=dev, dtype=torch.float64)
+    xyz[:, 2] *= 2.0 * S
+    lo = 2.0 * torch.arange(S, device=dev, dtype=torch.float64)
+    hi = lo + 2.0
+    geom = np.array([0.0, 2.0, 2.0 * (S - 1)])
+    wsb = L.pcfit_bin2_workspace_bytes(n, S, 0, n + n // 8)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    off = torch.empty(S + 1, dtype=torch.int64, device=dev)
+    status = torch.empty(1, dtype=torch.int32, device=dev)
+    xo, yo = torch.empty(n, dtype=torch.float64, device=dev), torch.empty(n, dtype=torch.float64, device=dev)
+
+    def count():
+        F.check(L.pcfit_bin2_count_dev(ptr(xyz), n, ptr(lo), ptr(hi), S, F._p(geom), 0, n + n // 8, ptr(off), ptr(status),
+                                       ptr(ws), wsb, stream))
+
+    def scatter():
+        F.check(L.pcfit_bin2_scatter_dev(n, S, F._p(geom), 0, n + n // 8, ptr(off), ptr(xo), ptr(yo), None, ptr(ws), wsb,
+                                         stream))
+    ms_count = timed(count, 3)
+    ms_scatter = timed(scatter, 3)
+    ms = ms_count + ms_scatter
+    out["binning_100M_points_2000_windows_random_z_order"] = {
+        "ms": ms, "ms_level1_and_counts": ms_count, "ms_level2_scatter": ms_scatter,
+        "points_per_s": n / (ms * 1e-3), "status": int(status.item()), "members": int(off[-1].item()),
+        "gbs_at_64_bytes_per_point_single_pass": 64.0 * n / (ms * 1e-3) / 1e9,
+        "hbm_frac_at_64_bytes_per_point": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
     return out
 
 

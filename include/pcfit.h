@@ -101,6 +101,29 @@ int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const double *z_l
                           int64_t n_slices, const double *window_geom, const int64_t *offsets, double *x_out,
                           double *y_out, int64_t *perm, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same two steps for many windows and large scans, in two levels (the
+ * host-level calls take this form by themselves from 8 M points and 257
+ * windows on): step 1 sorts x, y and a 16-bit key of every member into groups
+ * of 64 or 128 consecutive windows inside the workspace and counts; step 2
+ * sorts every group into its windows.  Members, order and bytes are those of
+ * pcfit_bin_count_dev / pcfit_bin_scatter_dev (analyzer.py:49-52); the output
+ * leaves in runs of 32 to 64 points instead of point by point.  Nothing is
+ * read back in between: the counts stay on the device.
+ * max_entries: how many (point, group) entries the workspace holds; <= 0 for
+ * 2 * n_points, which always suffices (a point on the edge shared by two
+ * groups makes two entries, any other member one, a point in no window
+ * none).  status (device, one int32): 0; 1 when the entries exceed
+ * max_entries, 2 when one group has 2^32 entries or more - offsets are then
+ * all zero and nothing is scattered.  want_perm must be the same in both
+ * steps (and in the workspace size); perm may be NULL in step 2. */
+size_t pcfit_bin2_workspace_bytes(int64_t n_points, int64_t n_slices, int want_perm, int64_t max_entries);
+int pcfit_bin2_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                         int64_t n_slices, const double *window_geom, int want_perm, int64_t max_entries,
+                         int64_t *offsets, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int pcfit_bin2_scatter_dev(int64_t n_points, int64_t n_slices, const double *window_geom, int want_perm,
+                           int64_t max_entries, const int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- algebraic fit: fit_circle_pratt, circle_fitting.py:35-54 -------- */
 /* cxcyr: S*3 (cx, cy, R).  status (nullable): 0, 1 (n < 3) or 4 (exactly
  * singular normal equations: the minimum-norm solution is returned, as the

@@ -49,6 +49,9 @@ SIGNATURES = {
     "pcfit_bin_workspace_bytes": (_sz, [_i64, _i64]),
     "pcfit_bin_count_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "pcfit_bin_scatter_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pcfit_bin2_workspace_bytes": (_sz, [_i64, _i64, C.c_int, _i64]),
+    "pcfit_bin2_count_dev": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pcfit_bin2_scatter_dev": (C.c_int, [_i64, _i64, _vp, C.c_int, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pcfit_kasa_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "pcfit_lm_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp]),
     "pcfit_fit_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f64, _i32, _f64, _f64, _f64, _vp, _vp, _vp, _vp,

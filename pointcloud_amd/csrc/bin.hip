@@ -37,11 +37,13 @@ namespace pcfit {
 constexpr int BIN_SEG = 64;            // chunk rows per scan segment
 constexpr int BIN_UNROLL = 4;          // 64-point trips whose loads are issued together
 constexpr int64_t BIN_MAX_SLICES = 16384;
+constexpr int BIN_GROUP_MAX = 128;     // windows per group of the two-level form, at most
 constexpr double BIN_EDGE_EPS = 1e-6;  // in units of the window step
-// Points from which more than BIN_STG_MAX_SLICES windows are binned in two levels. Measured on resident scans in
-// random z order: 100 M points / 2000 windows 10.7 -> 9.3 ms per analysis, 50 M / 400 windows 3.53 -> 3.36 ms,
-// 10 M / 400 windows 1.60 -> 1.70 ms (the second count pass and the extra launches cost more than they save).
-constexpr int64_t BIN_TWO_LEVEL_MIN = 32'000'000;
+// Points from which more than BIN_STG_MAX_SLICES windows are binned in two levels.  Measured on resident scans in
+// random z order, one analysis with one level / with two: 100 M points / 2000 windows 10.7 / 7.3 ms, 20 M / 1000
+// windows 2.25 / 1.94 ms, 10 M / 400 windows 1.58 / 1.48 ms, 5 M / 400 windows 1.31 / 1.33 ms, 5 M / 2000 windows
+// 3.84 / 3.99 ms (the second count pass and the extra launches cost more than they save).
+constexpr int64_t BIN_TWO_LEVEL_MIN = 8'000'000;
 
 struct BinGeom {
     double lo0, inv_step, rel_width;   // rel_width = (z_hi[0]-z_lo[0]) / step
@@ -103,14 +105,37 @@ __device__ __forceinline__ void windows_of(double z, const BinGeom &g, const dou
     }
 }
 
+// Two levels (bin_two_level): level 1 sends every member of a window to the group of 1 << wshift consecutive
+// windows that holds the window, with a 16-bit key - the window's number within the group, bit 15 when the point
+// is in the next window of the same group as well.  A point in the last window of a group and in the first of the
+// next becomes one entry in each.  Level 2 reads the keys in place of z.
+struct BinGroups {
+    int32_t G, wshift;              // number of groups, log2 of the windows per group
+    const uint16_t *key_in;         // level 2
+    uint16_t *key_out;              // level 1
+    const int64_t *goff, *cbase;    // level 2: first entry and first chunk of every group (G + 1 each)
+    int64_t cap1;                   // level 1: entries the level-1 arrays hold (more found: nothing is written)
+};
+
+// group (and key) of a member of window k1 / of windows k1 and k1 + 1; `two`: an entry in group b + 1 as well
+__device__ __forceinline__ void group_of(int32_t k1, bool has2, int32_t wshift, int32_t &b, bool &two, uint32_t &key16)
+{
+    b = k1 >> wshift;
+    two = has2 && ((k1 + 1) >> wshift) != b;
+    key16 = (uint32_t)(k1 - (b << wshift)) | ((has2 && !two) ? 0x8000u : 0u);
+}
+
+// GROUPS: count per group instead of per window (gr.G groups; counts has gr.G columns)
+template <bool GROUPS>
 __global__ __launch_bounds__(64) void bin_count_kernel(BinSrc src, int64_t n, int64_t chunk_len,
                                                       const double *__restrict__ z_lo,
-                                                      const double *__restrict__ z_hi, BinGeom g,
+                                                      const double *__restrict__ z_hi, BinGeom g, BinGroups gr,
                                                       uint32_t *__restrict__ counts)
 {
     extern __shared__ uint32_t lhist[];
     const int64_t c = blockIdx.x;
-    for (int64_t s = threadIdx.x; s < g.S; s += 64)
+    const int64_t cols = GROUPS ? (int64_t)gr.G : g.S;
+    for (int64_t s = threadIdx.x; s < cols; s += 64)
         lhist[s] = 0;
     __syncthreads();
     const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
@@ -128,6 +153,12 @@ __global__ __launch_bounds__(64) void bin_count_kernel(BinSrc src, int64_t n, in
             bool has2;
             windows_of(z[u], g, z_lo, z_hi, k1, has2);
             if (k1 >= 0) {
+                if constexpr (GROUPS) {
+                    int32_t b;
+                    uint32_t key16;
+                    group_of(k1, has2, gr.wshift, b, has2, key16);
+                    k1 = b;
+                }
                 atomicAdd(&lhist[k1], 1u);
                 if (has2)
                     atomicAdd(&lhist[k1 + 1], 1u);
@@ -135,8 +166,107 @@ __global__ __launch_bounds__(64) void bin_count_kernel(BinSrc src, int64_t n, in
         }
     }
     __syncthreads();
-    for (int64_t s = threadIdx.x; s < g.S; s += 64)
-        counts[c * g.S + s] = lhist[s];
+    for (int64_t s = threadIdx.x; s < cols; s += 64)
+        counts[c * cols + s] = lhist[s];
+}
+
+// the group of level-2 chunk c: the last one whose first chunk is not after c
+__device__ __forceinline__ int32_t group_of_chunk(const int64_t *__restrict__ cbase, int32_t G, int64_t c)
+{
+    int32_t lo = 0, hi = G - 1;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi + 1) >> 1;
+        if (cbase[mid] <= c)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    return lo;
+}
+
+// level 2, count: one wave per chunk of a group's entries; counts[c][k] for the 1 << wshift windows of the group
+__global__ __launch_bounds__(64) void bin2_count_kernel(BinGroups gr, int64_t chunk_len, uint32_t *__restrict__ counts)
+{
+    __shared__ uint32_t lhist[BIN_GROUP_MAX + 1];
+    const int W = 1 << gr.wshift;
+    const int64_t c = blockIdx.x;
+    if (c >= gr.cbase[gr.G])
+        return;                     // (a launch sized for the most chunks there can be)
+    for (int s = threadIdx.x; s <= W; s += 64)
+        lhist[s] = 0;
+    __syncthreads();
+    const int32_t grp = group_of_chunk(gr.cbase, gr.G, c);
+    const int64_t begin = gr.goff[grp] + (c - gr.cbase[grp]) * chunk_len, end = min(gr.goff[grp + 1], begin + chunk_len);
+    constexpr int UN = 8;
+    for (int64_t base = begin + threadIdx.x; base < end; base += 64 * UN) {
+        uint32_t k[UN];
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            const int64_t i = base + 64 * u;
+            k[u] = i < end ? (uint32_t)gr.key_in[i] : 0xffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; u++) {
+            if (k[u] == 0xffffu)
+                continue;
+            const uint32_t k1 = k[u] & 0x7fffu;
+            atomicAdd(&lhist[k1], 1u);
+            if (k[u] >> 15)
+                atomicAdd(&lhist[k1 + 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < W; s += 64)
+        counts[c * W + s] = lhist[s];
+}
+
+// level 2, scan: one wave per window; down the chunk rows of the window's group, counts[c][k] <- members in the
+// group's chunks before c, totals[window] = all of them
+__global__ __launch_bounds__(64) void bin2_colscan_kernel(BinGroups gr, int64_t S, uint32_t *__restrict__ counts,
+                                                         int64_t *__restrict__ totals)
+{
+    const int64_t s = blockIdx.x;
+    const int W = 1 << gr.wshift, lane = threadIdx.x;
+    const int32_t grp = (int32_t)(s >> gr.wshift), k = (int32_t)(s & (W - 1));
+    const int64_t c0 = gr.cbase[grp], c1 = gr.cbase[grp + 1];
+    int64_t run = 0;
+    for (int64_t base = c0; base < c1; base += 64) {
+        const int64_t c = base + lane;
+        const uint32_t v = c < c1 ? counts[c * W + k] : 0u;
+        int64_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += t;
+        }
+        if (c < c1)
+            counts[c * W + k] = (uint32_t)(run + incl - v);
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0 && s < S)
+        totals[s] = run;
+}
+
+// level 2, chunks: first chunk of every group from the groups' first entries; status 1 (and no chunks at all) when
+// the entries exceed what the level-1 arrays hold, 2 when a group has 2^32 entries or more
+__global__ void bin2_plan_kernel(const int64_t *__restrict__ goff, int32_t G, int64_t cap1, int64_t chunk_len,
+                                 int64_t *__restrict__ cbase, int32_t *__restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    int32_t st = goff[G] > cap1 ? 1 : 0;
+    for (int32_t k = 0; k < G && st == 0; k++)
+        if (goff[k + 1] - goff[k] >= (1ll << 32))
+            st = 2;
+    int64_t c = 0;
+    for (int32_t k = 0; k < G; k++) {
+        cbase[k] = c;
+        if (st == 0)
+            c += (goff[k + 1] - goff[k] + chunk_len - 1) / chunk_len;
+    }
+    cbase[G] = c;
+    *status = st;
 }
 
 // segment sums: segsum[g][s] = sum of counts rows of segment g
@@ -373,25 +503,30 @@ constexpr int BIN_STG_MAX_SLICES = 256;      // window index fits the byte kept 
 
 template <int TILE> constexpr int bin_stage_cap() { return TILE + TILE / 16; }
 
-template <int TILE, int WAVES, bool PERM> static size_t bin_stage_lds(int64_t S)
+template <int TILE, int WAVES, bool PERM, int LEVEL = 0> static size_t bin_stage_lds(int64_t S)
 {
     const size_t cap = (size_t)bin_stage_cap<TILE>();
     return cap * 16 + (size_t)S * 16 + ((size_t)WAVES * S + (size_t)S + 1 + WAVES) * 4 +
-           (PERM ? cap * 4 : 0) + cap;
+           (PERM ? cap * 4 : 0) + (LEVEL == 1 ? cap * 2 : 0) + cap;
 }
 
-template <int NBITS, bool PERM, int TILE, int WAVES>
+// LEVEL 0: the windows themselves are the buckets.  LEVEL 1 / 2: the two levels of bin_two_level - at level 1 the
+// buckets are the gr.G groups (windows found as at level 0, over all windows; every entry's key goes to gr.key_out),
+// at level 2 the 1 << gr.wshift windows of the chunk's group (keys from gr.key_in, x and y from src, a group's
+// entries in chunks of chunk_len from gr.goff[group] on; counts has one row per chunk, scanned by
+// bin2_colscan_kernel; g.S = all windows).
+template <int NBITS, bool PERM, int TILE, int WAVES, int LEVEL = 0>
 __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
     BinSrc src, int64_t n, int64_t chunk_len, const double *__restrict__ z_lo,
     const double *__restrict__ z_hi, BinGeom g, const uint32_t *__restrict__ counts,
     const int64_t *__restrict__ segbase, const int64_t *__restrict__ offsets, double *__restrict__ x_out,
     double *__restrict__ y_out, int64_t *__restrict__ perm, double *__restrict__ z_out,
-    const int64_t *__restrict__ idx_in)
+    const int64_t *__restrict__ idx_in, BinGroups gr)
 {
     constexpr int TRIPS = TILE / (64 * WAVES);
     constexpr int CAP = bin_stage_cap<TILE>();
     extern __shared__ __align__(16) unsigned char stg_lds[];
-    const int S = (int)g.S;
+    const int S = LEVEL == 0 ? (int)g.S : LEVEL == 1 ? gr.G : (1 << gr.wshift);
     double2 *stage = reinterpret_cast<double2 *>(stg_lds);
     int64_t *gpos = reinterpret_cast<int64_t *>(stg_lds + (size_t)CAP * 16);   // next output slot per window
     int64_t *gdelta = gpos + S;                                                  // output slot - LDS slot
@@ -399,24 +534,60 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
     uint32_t *lstart = cnt + WAVES * S;                                  // S + 1
     uint32_t *wave_sum = lstart + S + 1;                                         // WAVES
     uint32_t *sidx = wave_sum + WAVES;                                   // CAP, with PERM
-    uint8_t *skey = reinterpret_cast<uint8_t *>(sidx + (PERM ? CAP : 0));        // CAP
+    uint16_t *sk16 = reinterpret_cast<uint16_t *>(sidx + (PERM ? CAP : 0));      // CAP, at level 1
+    uint8_t *skey = reinterpret_cast<uint8_t *>(sk16 + (LEVEL == 1 ? CAP : 0));  // CAP
 
-    const int64_t c = chunk_of_block(blockIdx.x, gridDim.x);
+    // (level 2: a launch may be sized for the most chunks there can be; the chunks there are share the XCDs evenly)
+    const int64_t n_chunks = LEVEL == 2 ? gr.cbase[gr.G] : (int64_t)gridDim.x;
+    if (LEVEL == 2 && (int64_t)blockIdx.x >= n_chunks)
+        return;
+    const int64_t c = chunk_of_block(blockIdx.x, n_chunks);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t below = (1ull << lane) - 1ull;
     uint32_t *cw = cnt + w * S;
-    for (int s = tid; s < S; s += 64 * WAVES)
-        gpos[s] = offsets[s] + segbase[(c / BIN_SEG) * g.S + s] + (int64_t)counts[c * g.S + s];
-    const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
+    int64_t begin, end;
+    if constexpr (LEVEL == 1) {
+        if (offsets[S] > gr.cap1)
+            return;                 // more entries than the level-1 arrays hold: the plan kernel has reported it
+    }
+    if constexpr (LEVEL == 2) {
+        const int32_t grp = group_of_chunk(gr.cbase, gr.G, c);
+        const int64_t s0 = (int64_t)grp << gr.wshift;
+        for (int s = tid; s < S; s += 64 * WAVES)
+            gpos[s] = s0 + s < g.S ? offsets[s0 + s] + (int64_t)counts[c * S + s] : 0;
+        begin = gr.goff[grp] + (c - gr.cbase[grp]) * chunk_len;
+        end = min(gr.goff[grp + 1], begin + chunk_len);
+    } else {
+        for (int s = tid; s < S; s += 64 * WAVES)
+            gpos[s] = offsets[s] + segbase[(c / BIN_SEG) * S + s] + (int64_t)counts[c * (int64_t)S + s];
+        begin = c * chunk_len;
+        end = min(n, begin + chunk_len);
+    }
     for (int64_t tbase = begin; tbase < end; tbase += TILE) {
         for (int s = tid; s < WAVES * S; s += 64 * WAVES)
             cnt[s] = 0;
         __syncthreads();
         // pass 1
         double px[TRIPS], py[TRIPS];
-        uint32_t key[TRIPS], r1[TRIPS], r2[TRIPS];      // key: window + 1, bit 31 = also in the next window
+        uint32_t key[TRIPS], r1[TRIPS], r2[TRIPS];      // key: bucket + 1, bit 31 = also in the next bucket
+        uint32_t key16[LEVEL == 1 ? TRIPS : 1];         // level 1: what level 2 will read
         const int64_t wbase = tbase + (int64_t)w * (TRIPS * 64);
-        {
+        if constexpr (LEVEL == 2) {
+            uint32_t kk[TRIPS];
+#pragma unroll
+            for (int u = 0; u < TRIPS; u++) {
+                const int64_t i = wbase + 64 * u + lane;
+                const int64_t ic = i < end ? i : end - 1;
+                px[u] = src.x[ic];
+                py[u] = src.y[ic];
+                kk[u] = gr.key_in[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < TRIPS; u++) {
+                const int64_t i = wbase + 64 * u + lane;
+                key[u] = i < end ? ((kk[u] & 0x7fffu) + 1u) | ((kk[u] >> 15) ? 0x80000000u : 0u) : 0u;
+            }
+        } else {
             // every load of the tile is issued before the first is used; lanes past the end read the
             // chunk's last point and get NaN for z: no window
             double pz[TRIPS];
@@ -434,6 +605,14 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 int32_t k1;
                 bool has2;
                 windows_of(i < end ? pz[u] : __longlong_as_double(0x7ff8000000000000ll), g, z_lo, z_hi, k1, has2);
+                if constexpr (LEVEL == 1) {
+                    key16[u] = 0u;
+                    if (k1 >= 0) {
+                        int32_t b;
+                        group_of(k1, has2, gr.wshift, b, has2, key16[u]);
+                        k1 = b;
+                    }
+                }
                 key[u] = (uint32_t)(k1 + 1) | (has2 ? 0x80000000u : 0u);
             }
         }
@@ -541,10 +720,12 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 stage[p1] = make_double2(px[u], py[u]);
                 skey[p1] = (uint8_t)k1;
                 if (PERM) sidx[p1] = local;
+                if (LEVEL == 1) sk16[p1] = (uint16_t)key16[LEVEL == 1 ? u : 0];
                 if (has2) {
                     stage[p2] = make_double2(px[u], py[u]);
                     skey[p2] = (uint8_t)(k1 + 1);
                     if (PERM) sidx[p2] = local;
+                    if (LEVEL == 1) sk16[p2] = 0;           // the first window of the next group, and no other
                 }
             } else {
                 const int64_t d1 = gdelta[k1] + (int64_t)p1;
@@ -553,12 +734,14 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 y_out[d1] = py[u];
                 if (PERM && perm) perm[d1] = idx_in ? idx_in[from] : from;
                 if (PERM && z_out) z_out[d1] = src.z[from * src.stride];
+                if (LEVEL == 1) gr.key_out[d1] = (uint16_t)key16[LEVEL == 1 ? u : 0];
                 if (has2) {
                     const int64_t d2 = gdelta[k1 + 1] + (int64_t)p2;
                     x_out[d2] = px[u];
                     y_out[d2] = py[u];
                     if (PERM && perm) perm[d2] = idx_in ? idx_in[from] : from;
                     if (PERM && z_out) z_out[d2] = src.z[from * src.stride];
+                    if (LEVEL == 1) gr.key_out[d2] = 0;
                 }
             }
         }
@@ -570,6 +753,7 @@ __global__ __launch_bounds__(64 * WAVES) void bin_scatter_staged_kernel(
                 const int64_t d = gdelta[skey[e]] + (int64_t)e;
                 x_out[d] = v.x;
                 y_out[d] = v.y;
+                if (LEVEL == 1) gr.key_out[d] = sk16[e];
                 if (PERM) {
                     // (with PERM the source index of every staged point is kept: it serves perm, and z of the
                     // point when the caller wants z scattered as well - a re-read of what this tile just loaded)
@@ -663,10 +847,12 @@ PCFIT_API size_t pcfit_bin_workspace_bytes(int64_t n_points, int64_t n_slices)
 
 namespace pcfit {
 
-// the count pass and its scans: offsets (device, S + 1) and the workspace the scatter pass reads
+// the count pass and its scans: offsets (device, S + 1) and the workspace the scatter pass reads.
+// wshift >= 0: level 1 of the two-level form - counts, scans and offsets (G + 1) are those of the G groups of
+// 1 << wshift windows.
 static int count_launch(const BinSrc &src, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
                         const double *window_geom, int64_t *offsets, void *workspace, size_t workspace_bytes,
-                        hipStream_t st)
+                        hipStream_t st, int wshift = -1)
 {
     PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     if (n_slices > BIN_MAX_SLICES) {
@@ -674,7 +860,8 @@ static int count_launch(const BinSrc &src, int64_t n_points, const double *z_lo,
         return PCFIT_ERR_UNSUPPORTED;
     }
     PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && (src.x || n_points == 0), "bin: null pointer");
-    const BinPlan p = bin_plan(n_points, n_slices);
+    const int64_t S = wshift >= 0 ? ((n_slices - 1) >> wshift) + 1 : n_slices;     // columns: windows or groups
+    const BinPlan p = bin_plan(n_points, S);
     if (!workspace || workspace_bytes < p.bytes) {
         set_error("bin: workspace of %zu bytes needed", p.bytes);
         return PCFIT_ERR_WORKSPACE;
@@ -686,9 +873,13 @@ static int count_launch(const BinSrc &src, int64_t n_points, const double *z_lo,
     uint32_t *counts = reinterpret_cast<uint32_t *>(ws + p.counts_off);
     int64_t *segsum = reinterpret_cast<int64_t *>(ws + p.segsum_off);
     int64_t *totals = reinterpret_cast<int64_t *>(ws + p.totals_off);
-    const int64_t S = n_slices;
-    bin_count_kernel<<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(src, n_points, p.chunk_len, z_lo, z_hi,
-                                                                              g, counts);
+    const BinGroups gr{(int32_t)S, wshift, nullptr, nullptr, nullptr, nullptr, 0};
+    if (wshift >= 0)
+        bin_count_kernel<true><<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(src, n_points, p.chunk_len,
+                                                                                        z_lo, z_hi, g, gr, counts);
+    else
+        bin_count_kernel<false><<<dim3((unsigned)p.chunks), dim3(64), (size_t)S * 4, st>>>(src, n_points, p.chunk_len,
+                                                                                         z_lo, z_hi, g, gr, counts);
     PCFIT_LAUNCH_CHECK();
     const dim3 cols((unsigned)((S + 255) / 256), (unsigned)p.segs);
     bin_segsum_kernel<<<cols, dim3(256), 0, st>>>(counts, p.chunks, S, segsum);
@@ -745,7 +936,7 @@ static int scatter_launch(const BinSrc &src, int64_t n_points, const double *z_l
                 }
                 kern<<<dim3((unsigned)p.chunks), dim3(64 * waves), lds, st>>>(src, n_points, p.chunk_len, z_lo, z_hi, g,
                                                                               counts, segsum, offsets, x_out, y_out,
-                                                                              perm, z_out, idx_in);
+                                                                              perm, z_out, idx_in, BinGroups{});
             };
             // Tiles of 2048 points on four waves. Measured against 4096 x 4 and 4096 x 8: longer tiles make
             // longer runs (50 M points in random order, 57 windows, no perm: 0.47 vs 0.56 ms) but leave one or two
@@ -772,107 +963,127 @@ static int scatter_launch(const BinSrc &src, int64_t n_points, const double *z_l
     return PCFIT_OK;
 }
 
+// the staged kernel at one of the two levels (chunks workgroups)
+template <int LEVEL>
+static int staged_level_launch(const BinSrc &src, int64_t n, int64_t chunks, int64_t chunk_len, const double *z_lo,
+                               const double *z_hi, const BinGeom &g, const uint32_t *counts, const int64_t *segsum,
+                               const int64_t *offsets, double *x_out, double *y_out, int64_t *perm,
+                               const int64_t *idx_in, const BinGroups &gr, hipStream_t st)
+{
+    const int buckets = LEVEL == 1 ? gr.G : 1 << gr.wshift;
+    int nbits = 1;
+    while ((1 << nbits) < buckets + 2)
+        nbits++;
+    int rc = PCFIT_OK;
+    with_key_bits(nbits, [&](auto tag) {
+        constexpr int NB = decltype(tag)::value < 8 ? decltype(tag)::value : 8;     // 130 keys at most
+        auto launch = [&](auto kern, size_t lds) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                set_error("bin: %zu bytes of LDS refused", lds);
+                rc = PCFIT_ERR_HIP;
+                return;
+            }
+            kern<<<dim3((unsigned)chunks), dim3(256), lds, st>>>(src, n, chunk_len, z_lo, z_hi, g, counts, segsum,
+                                                                 offsets, x_out, y_out, perm, nullptr, idx_in, gr);
+        };
+        // Tiles of 2048 points on four waves, 4096 at level 2 without perm.  Measured on 100 M points in random z
+        // order, 2000 windows: level 2 0.97 ms with tiles of 2048, 0.73 ms with 4096 (runs of 64 points instead of
+        // 32); with perm 1.51 against 1.88 ms (one workgroup per CU); level 1 1.09 against 1.82 ms.
+        if (perm)
+            launch(&bin_scatter_staged_kernel<NB, true, 2048, 4, LEVEL>, bin_stage_lds<2048, 4, true, LEVEL>(buckets));
+        else if (LEVEL == 2)
+            launch(&bin_scatter_staged_kernel<NB, false, 4096, 4, LEVEL>, bin_stage_lds<4096, 4, false, LEVEL>(buckets));
+        else
+            launch(&bin_scatter_staged_kernel<NB, false, 2048, 4, LEVEL>, bin_stage_lds<2048, 4, false, LEVEL>(buckets));
+    });
+    if (rc) return rc;
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+constexpr int64_t BIN_L2_CHUNK = 4096;       // entries per level-2 workgroup
+
 // Two levels for many windows.  With more than BIN_STG_MAX_SLICES windows the scatter cannot order its tiles in
 // LDS, and storing every point on its own costs several times the output in HBM writes when the points come in no
-// z order.  Level 1 scatters x, y, z (and the source index when perm is wanted) into groups of BIN_STG_MAX_SLICES
-// consecutive windows, each group one closed window from the first window's lower to the last one's upper edge;
-// level 2 bins every group into its own windows.  Both levels run the staged kernel.  A point on the edge shared
-// by two groups goes into both and each group keeps it for its own window only, so the result - members, order,
-// bytes - is that of the single pass.
+// z order.  Level 1 finds every point's window(s) as the single pass does and scatters x, y and a 16-bit key (and
+// the source index when perm is wanted) into groups of 64 or 128 consecutive windows; level 2 bins every group's
+// entries into the group's windows by their keys.  Both levels run the staged kernel, level 2 for all groups in
+// one launch.  Windows are decided once, by the same code on the same z, and both levels are stable, so the
+// result - members, order, bytes - is that of the single pass.
 static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                          bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
                          DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st)
 {
-    const int64_t W = BIN_STG_MAX_SLICES, G = (S + W - 1) / W;
-    // level 1: the groups as windows (the last one padded to the common width; what it takes in beyond the last
-    // real window finds no window at level 2)
-    std::vector<double> glo((size_t)G), ghi((size_t)G);
-    for (int64_t g = 0; g < G; g++) {
-        glo[(size_t)g] = z_lo[g * W];
-        ghi[(size_t)g] = (g + 1) * W <= S ? z_hi[(g + 1) * W - 1] : glo[(size_t)g] + (ghi[0] - glo[0]);
-    }
-    double geom1[3];
-    PCFIT_TRY(bin_check_windows(glo.data(), ghi.data(), G, geom1));
-    DevBuf dglo, dghi, dgoff, dws1, x1, y1, z1, i1;
-    PCFIT_TRY(dglo.upload(glo.data(), (size_t)G * 8, st));
-    PCFIT_TRY(dghi.upload(ghi.data(), (size_t)G * 8, st));
-    PCFIT_TRY(dgoff.alloc((size_t)(G + 1) * 8));
-    PCFIT_TRY(dws1.alloc(bin_plan(n_points, G).bytes));
+    const int wshift = S <= 4096 ? 6 : 7;
+    const int64_t W = 1ll << wshift, G = ((S - 1) >> wshift) + 1;
+    double geom[3];
+    PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
+    BinGeom g;
+    PCFIT_TRY(bin_geom(geom, S, g));
     const BinSrc rows = rows_of(dxyz);
-    PCFIT_TRY(count_launch(rows, n_points, dglo.as<double>(), dghi.as<double>(), G, geom1, dgoff.as<int64_t>(), dws1.p,
-                           dws1.bytes, st));
-    std::vector<int64_t> goff((size_t)G + 1);
+    // level 1
+    const BinPlan p1 = bin_plan(n_points, G);
+    DevBuf dgoff, dws1, x1, y1, k1, i1;
+    PCFIT_TRY(dgoff.alloc((size_t)(G + 1) * 8));
+    PCFIT_TRY(dws1.alloc(p1.bytes));
+    PCFIT_TRY(count_launch(rows, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, dgoff.as<int64_t>(), dws1.p,
+                           dws1.bytes, st, wshift));
+    std::vector<int64_t> goff((size_t)G + 1), cbase((size_t)G + 1, 0);
     PCFIT_TRY(dgoff.download(goff.data(), goff.size() * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     const int64_t n1 = goff[(size_t)G];
+    for (int64_t k = 0; k < G; k++) {
+        const int64_t ng = goff[(size_t)k + 1] - goff[(size_t)k];
+        PCFIT_REQUIRE(ng < (1ll << 32), "bin: more than 2^32 points in %lld consecutive windows", (long long)W);
+        cbase[(size_t)k + 1] = cbase[(size_t)k] + (ng + BIN_L2_CHUNK - 1) / BIN_L2_CHUNK;
+    }
+    const int64_t C2 = cbase[(size_t)G];
     PCFIT_TRY(x1.alloc((size_t)n1 * 8));
     PCFIT_TRY(y1.alloc((size_t)n1 * 8));
-    PCFIT_TRY(z1.alloc((size_t)n1 * 8));
+    PCFIT_TRY(k1.alloc((size_t)n1 * 2));
     if (want_perm) PCFIT_TRY(i1.alloc((size_t)n1 * 8));
-    if (n1 > 0)
-        PCFIT_TRY(scatter_launch(rows, n_points, dglo.as<double>(), dghi.as<double>(), G, geom1, dgoff.as<int64_t>(),
-                                 x1.as<double>(), y1.as<double>(), want_perm ? i1.as<int64_t>() : nullptr,
-                                 z1.as<double>(), nullptr, dws1.p, dws1.bytes, st));
-    // level 2, counts: every group against its own windows (one workspace and one offsets array, a part each)
-    std::vector<size_t> ws_at((size_t)G + 1, 0);
-    for (int64_t g = 0; g < G; g++) {
-        const int64_t Sg = std::min<int64_t>(W, S - g * W), ng = goff[(size_t)g + 1] - goff[(size_t)g];
-        ws_at[(size_t)g + 1] = ws_at[(size_t)g] + (ng > 0 ? bin_plan(ng, Sg).bytes : 0);
+    if (n1 > 0) {
+        const BinGroups gr1{(int32_t)G, wshift, nullptr, k1.as<uint16_t>(), nullptr, nullptr, n1};
+        const char *ws = static_cast<const char *>(dws1.p);
+        PCFIT_TRY(staged_level_launch<1>(rows, n_points, p1.chunks, p1.chunk_len, dlo.as<double>(), dhi.as<double>(), g,
+                                         reinterpret_cast<const uint32_t *>(ws + p1.counts_off),
+                                         reinterpret_cast<const int64_t *>(ws + p1.segsum_off), dgoff.as<int64_t>(),
+                                         x1.as<double>(), y1.as<double>(), want_perm ? i1.as<int64_t>() : nullptr,
+                                         nullptr, gr1, st));
     }
-    DevBuf ws2, off2;
-    PCFIT_TRY(ws2.alloc(std::max<size_t>(ws_at[(size_t)G], 8)));
-    PCFIT_TRY(off2.alloc((size_t)(S + G) * 8));                      // group g's Sg + 1 offsets start at g * W + g
-    PCFIT_HIP(hipMemsetAsync(off2.p, 0, (size_t)(S + G) * 8, st));   // (groups without points are not counted)
-    std::vector<double> geom2((size_t)G * 3);
-    for (int64_t g = 0; g < G; g++) {
-        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0), ng = goff[(size_t)g + 1] - goff[(size_t)g];
-        double *gm = &geom2[(size_t)g * 3];
-        gm[0] = z_lo[s0];
-        gm[1] = z_hi[s0];
-        gm[2] = z_lo[s0 + Sg - 1];
-        if (ng == 0)
-            continue;
-        const BinSrc cols{x1.as<double>() + goff[(size_t)g], y1.as<double>() + goff[(size_t)g],
-                          z1.as<double>() + goff[(size_t)g], 1};
-        PCFIT_TRY(count_launch(cols, ng, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, gm,
-                               off2.as<int64_t>() + s0 + g, static_cast<char *>(ws2.p) + ws_at[(size_t)g],
-                               ws_at[(size_t)g + 1] - ws_at[(size_t)g], st));
+    // level 2: counts per chunk and window, scanned down every group's chunks; the windows' totals give the offsets
+    DevBuf dcbase, counts2, totals;
+    PCFIT_TRY(dcbase.upload(cbase.data(), cbase.size() * 8, st));
+    PCFIT_TRY(counts2.alloc(std::max<size_t>((size_t)C2 * (size_t)W * 4, 8)));
+    PCFIT_TRY(totals.alloc((size_t)S * 8));
+    const BinGroups gr2{(int32_t)G, wshift, k1.as<uint16_t>(), nullptr, dgoff.as<int64_t>(), dcbase.as<int64_t>(), n1};
+    if (C2 > 0) {
+        bin2_count_kernel<<<dim3((unsigned)C2), dim3(64), 0, st>>>(gr2, BIN_L2_CHUNK, counts2.as<uint32_t>());
+        PCFIT_LAUNCH_CHECK();
     }
-    std::vector<int64_t> hoff((size_t)(S + G));
-    PCFIT_TRY(off2.download(hoff.data(), hoff.size() * 8, st));
+    bin2_colscan_kernel<<<dim3((unsigned)(G * W)), dim3(64), 0, st>>>(gr2, S, counts2.as<uint32_t>(),
+                                                                      totals.as<int64_t>());
+    PCFIT_LAUNCH_CHECK();
+    bin_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(totals.as<int64_t>(), S, doff.as<int64_t>());
+    PCFIT_LAUNCH_CHECK();
+    PCFIT_TRY(doff.download(offsets, (size_t)(S + 1) * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
-    std::vector<int64_t> base((size_t)G + 1, 0);
-    for (int64_t g = 0; g < G; g++) {
-        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0);
-        const int64_t *og = &hoff[(size_t)(s0 + g)];
-        for (int64_t j = 0; j < Sg; j++)
-            offsets[s0 + j] = base[(size_t)g] + og[j];
-        base[(size_t)g + 1] = base[(size_t)g] + og[Sg];
-    }
-    const int64_t total = base[(size_t)G];
-    offsets[S] = total;
+    const int64_t total = offsets[S];
     if (capacity >= 0 && total > capacity)
         return PCFIT_OK;                       // (the caller reports it; nothing is scattered)
-    PCFIT_TRY(doff.upload(offsets, (size_t)(S + 1) * 8, st));
     PCFIT_TRY(dx.alloc((size_t)total * 8));
     PCFIT_TRY(dy.alloc((size_t)total * 8));
     if (want_perm) PCFIT_TRY(dperm.alloc((size_t)total * 8));
-    // level 2, scatter: group g writes at base[g] with its own offsets
-    for (int64_t g = 0; g < G; g++) {
-        const int64_t s0 = g * W, Sg = std::min<int64_t>(W, S - s0), ng = goff[(size_t)g + 1] - goff[(size_t)g];
-        if (ng == 0 || base[(size_t)g + 1] == base[(size_t)g])
-            continue;
-        const BinSrc cols{x1.as<double>() + goff[(size_t)g], y1.as<double>() + goff[(size_t)g],
-                          z1.as<double>() + goff[(size_t)g], 1};
-        PCFIT_TRY(scatter_launch(cols, ng, dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, &geom2[(size_t)g * 3],
-                                 off2.as<int64_t>() + s0 + g, dx.as<double>() + base[(size_t)g],
-                                 dy.as<double>() + base[(size_t)g],
-                                 want_perm ? dperm.as<int64_t>() + base[(size_t)g] : nullptr, nullptr,
-                                 want_perm ? i1.as<int64_t>() + goff[(size_t)g] : nullptr,
-                                 static_cast<char *>(ws2.p) + ws_at[(size_t)g],
-                                 ws_at[(size_t)g + 1] - ws_at[(size_t)g], st));
+    if (total > 0) {
+        const BinSrc cols{x1.as<double>(), y1.as<double>(), nullptr, 1};
+        PCFIT_TRY(staged_level_launch<2>(cols, n1, C2, BIN_L2_CHUNK, nullptr, nullptr, g, counts2.as<uint32_t>(),
+                                         nullptr, doff.as<int64_t>(), dx.as<double>(), dy.as<double>(),
+                                         want_perm ? dperm.as<int64_t>() : nullptr,
+                                         want_perm ? i1.as<int64_t>() : nullptr, gr2, st));
     }
-    // (the level-1 arrays are released when this returns: the stream runs the scatters first, as every other
+    // (the level-1 arrays are released when this returns: the stream runs the scatter first, as every other
     // block handed back to the cache relies on)
     return PCFIT_OK;
 }
@@ -988,6 +1199,126 @@ PCFIT_API int pcfit_bin_scatter_dev(const double *xyz, int64_t n_points, const d
     PCFIT_ENTER();
     return scatter_launch(rows_of(xyz), n_points, z_lo, z_hi, n_slices, window_geom, offsets, x_out, y_out, perm,
                           nullptr, nullptr, workspace, workspace_bytes, as_stream(stream));
+}
+
+// ---- the two-level form for callers that hold everything on the device (no read-back in between) ----
+namespace pcfit {
+
+struct Bin2Plan {
+    int wshift;
+    int64_t W, G, cap1, max_chunks;
+    BinPlan p1;
+    size_t ws1_off, goff_off, cbase_off, totals_off, counts2_off, x1_off, y1_off, i1_off, k1_off, bytes;
+};
+
+static Bin2Plan bin2_plan(int64_t n, int64_t S, bool want_perm, int64_t max_entries)
+{
+    Bin2Plan q;
+    q.wshift = S <= 4096 ? 6 : 7;
+    q.W = 1ll << q.wshift;
+    q.G = ((std::max<int64_t>(S, 1) - 1) >> q.wshift) + 1;
+    q.cap1 = max_entries > 0 ? max_entries : 2 * std::max<int64_t>(n, 0);      // a point makes two entries at most
+    q.max_chunks = q.cap1 / BIN_L2_CHUNK + q.G;
+    q.p1 = bin_plan(n, q.G);
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += up(bytes); return o; };
+    q.ws1_off = take(q.p1.bytes);
+    q.goff_off = take((size_t)(q.G + 1) * 8);
+    q.cbase_off = take((size_t)(q.G + 1) * 8);
+    q.totals_off = take((size_t)std::max<int64_t>(S, 1) * 8);
+    q.counts2_off = take((size_t)q.max_chunks * (size_t)q.W * 4);
+    q.x1_off = take((size_t)q.cap1 * 8);
+    q.y1_off = take((size_t)q.cap1 * 8);
+    q.i1_off = take(want_perm ? (size_t)q.cap1 * 8 : 0);
+    q.k1_off = take((size_t)q.cap1 * 2);
+    q.bytes = at;
+    return q;
+}
+
+static int bin2_check(int64_t n_points, int64_t n_slices, const void *workspace, size_t workspace_bytes,
+                      const Bin2Plan &q)
+{
+    PCFIT_REQUIRE(n_points >= 0 && n_slices >= 1, "bin: need n_points >= 0 and n_slices >= 1");
+    if (n_slices > BIN_MAX_SLICES) {
+        set_error("bin: at most %lld windows per call (got %lld)", (long long)BIN_MAX_SLICES, (long long)n_slices);
+        return PCFIT_ERR_UNSUPPORTED;
+    }
+    if (!workspace || workspace_bytes < q.bytes) {
+        set_error("bin: workspace of %zu bytes needed", q.bytes);
+        return PCFIT_ERR_WORKSPACE;
+    }
+    return PCFIT_OK;
+}
+
+}  // namespace pcfit
+
+PCFIT_API size_t pcfit_bin2_workspace_bytes(int64_t n_points, int64_t n_slices, int want_perm, int64_t max_entries)
+{
+    return bin2_plan(std::max<int64_t>(n_points, 0), n_slices, want_perm != 0, max_entries).bytes;
+}
+
+PCFIT_API int pcfit_bin2_count_dev(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
+                                   int64_t n_slices, const double *window_geom, int want_perm, int64_t max_entries,
+                                   int64_t *offsets, int32_t *status, void *workspace, size_t workspace_bytes,
+                                   void *stream)
+{
+    PCFIT_ENTER();
+    const Bin2Plan q = bin2_plan(std::max<int64_t>(n_points, 0), n_slices, want_perm != 0, max_entries);
+    PCFIT_TRY(bin2_check(n_points, n_slices, workspace, workspace_bytes, q));
+    PCFIT_REQUIRE(z_lo && z_hi && window_geom && offsets && status && (xyz || n_points == 0), "bin: null pointer");
+    hipStream_t st = as_stream(stream);
+    BinGeom g;
+    PCFIT_TRY(bin_geom(window_geom, n_slices, g));
+    char *ws = static_cast<char *>(workspace);
+    int64_t *goff = reinterpret_cast<int64_t *>(ws + q.goff_off), *cbase = reinterpret_cast<int64_t *>(ws + q.cbase_off);
+    int64_t *totals = reinterpret_cast<int64_t *>(ws + q.totals_off);
+    uint32_t *counts2 = reinterpret_cast<uint32_t *>(ws + q.counts2_off);
+    double *x1 = reinterpret_cast<double *>(ws + q.x1_off), *y1 = reinterpret_cast<double *>(ws + q.y1_off);
+    int64_t *i1 = want_perm ? reinterpret_cast<int64_t *>(ws + q.i1_off) : nullptr;
+    uint16_t *k1 = reinterpret_cast<uint16_t *>(ws + q.k1_off);
+    const BinSrc rows = rows_of(xyz);
+    PCFIT_TRY(count_launch(rows, n_points, z_lo, z_hi, n_slices, window_geom, goff, ws + q.ws1_off, q.p1.bytes, st,
+                           q.wshift));
+    bin2_plan_kernel<<<dim3(1), dim3(64), 0, st>>>(goff, (int32_t)q.G, q.cap1, BIN_L2_CHUNK, cbase, status);
+    PCFIT_LAUNCH_CHECK();
+    const BinGroups gr1{(int32_t)q.G, q.wshift, nullptr, k1, nullptr, nullptr, q.cap1};
+    if (n_points > 0)
+        PCFIT_TRY(staged_level_launch<1>(rows, n_points, q.p1.chunks, q.p1.chunk_len, z_lo, z_hi, g,
+                                         reinterpret_cast<const uint32_t *>(ws + q.ws1_off + q.p1.counts_off),
+                                         reinterpret_cast<const int64_t *>(ws + q.ws1_off + q.p1.segsum_off), goff, x1, y1,
+                                         i1, nullptr, gr1, st));
+    const BinGroups gr2{(int32_t)q.G, q.wshift, k1, nullptr, goff, cbase, q.cap1};
+    bin2_count_kernel<<<dim3((unsigned)q.max_chunks), dim3(64), 0, st>>>(gr2, BIN_L2_CHUNK, counts2);
+    PCFIT_LAUNCH_CHECK();
+    bin2_colscan_kernel<<<dim3((unsigned)(q.G * q.W)), dim3(64), 0, st>>>(gr2, n_slices, counts2, totals);
+    PCFIT_LAUNCH_CHECK();
+    bin_offsets_kernel<<<dim3(1), dim3(1024), 0, st>>>(totals, n_slices, offsets);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_bin2_scatter_dev(int64_t n_points, int64_t n_slices, const double *window_geom, int want_perm,
+                                     int64_t max_entries, const int64_t *offsets, double *x_out, double *y_out,
+                                     int64_t *perm, void *workspace, size_t workspace_bytes, void *stream)
+{
+    PCFIT_ENTER();
+    const Bin2Plan q = bin2_plan(std::max<int64_t>(n_points, 0), n_slices, want_perm != 0, max_entries);
+    PCFIT_TRY(bin2_check(n_points, n_slices, workspace, workspace_bytes, q));
+    PCFIT_REQUIRE(window_geom && offsets && x_out && y_out, "bin: null pointer");
+    PCFIT_REQUIRE(!perm || want_perm, "bin: perm needs the count step run with want_perm");
+    BinGeom g;
+    PCFIT_TRY(bin_geom(window_geom, n_slices, g));
+    char *ws = static_cast<char *>(workspace);
+    const BinGroups gr2{(int32_t)q.G, q.wshift, reinterpret_cast<const uint16_t *>(ws + q.k1_off), nullptr,
+                        reinterpret_cast<const int64_t *>(ws + q.goff_off),
+                        reinterpret_cast<const int64_t *>(ws + q.cbase_off), q.cap1};
+    const BinSrc cols{reinterpret_cast<const double *>(ws + q.x1_off), reinterpret_cast<const double *>(ws + q.y1_off),
+                      nullptr, 1};
+    return staged_level_launch<2>(cols, q.cap1, q.max_chunks, BIN_L2_CHUNK, nullptr, nullptr, g,
+                                  reinterpret_cast<const uint32_t *>(ws + q.counts2_off), nullptr, offsets, x_out, y_out,
+                                  perm, perm ? reinterpret_cast<const int64_t *>(ws + q.i1_off) : nullptr, gr2,
+                                  as_stream(stream));
 }
 
 // bin on the device, slices to the host: the scan is on the device already

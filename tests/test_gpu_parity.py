@@ -269,6 +269,60 @@ def test_bin_slices_stable_and_exact():
     assert np.array_equal(x, q[perm, 0]) and np.array_equal(y, q[perm, 1])
 
 
+def test_two_level_binning_on_the_device_without_a_read_back():
+    """pcfit_bin2_count_dev / pcfit_bin2_scatter_dev: members, order and bytes of the CPU's binning for 2000 windows
+    with gaps, 700 windows sharing edges with z on a grid that hits them (also the edges between groups of 64), and
+    11 400 windows (groups of 128); with and without perm; a workspace too small for the entries reports it."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    L = F.lib()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pts = R.make_cylinder(300_000, 100, seed=23, outlier_frac=0.02)           # z in [0, 200]
+    pts[7, 2] = np.nan
+    grid = pts.copy()
+    grid[:, 2] = np.round(grid[:, 2] * 8.0) / 8.0
+    cases = ((pts, 0.1 * np.arange(2000), 0.08), (grid, 0.125 * np.arange(700), 0.125),
+             (pts[:60_000], 0.01 * np.arange(11_400), 0.01))
+    for arr, lo, width in cases:
+        hi = lo + width
+        o_ref, p_ref = N.bin_slices(arr, lo, hi)
+        n, S = len(arr), len(lo)
+        geom = np.array([lo[0], hi[0], lo[-1]])
+        xyz, dlo, dhi = d(arr), d(lo), d(hi)
+        for want_perm in (1, 0):
+            wsb = L.pcfit_bin2_workspace_bytes(n, S, want_perm, 0)
+            ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            off = torch.empty(S + 1, dtype=torch.int64, device=dev)
+            status = torch.full((1,), -1, dtype=torch.int32, device=dev)
+            F.check(L.pcfit_bin2_count_dev(p(xyz), n, p(dlo), p(dhi), S, F._p(geom), want_perm, 0, p(off), p(status),
+                                           p(ws), wsb, st))
+            assert status.item() == 0 and np.array_equal(off.cpu().numpy(), o_ref)
+            total = int(o_ref[-1])
+            x = torch.empty(total, dtype=torch.float64, device=dev)
+            y = torch.empty_like(x)
+            perm = torch.empty(total, dtype=torch.int64, device=dev) if want_perm else None
+            F.check(L.pcfit_bin2_scatter_dev(n, S, F._p(geom), want_perm, 0, p(off), p(x), p(y),
+                                             p(perm) if want_perm else None, p(ws), wsb, st))
+            assert np.array_equal(x.cpu().numpy(), arr[p_ref, 0]) and np.array_equal(y.cpu().numpy(), arr[p_ref, 1])
+            if want_perm:
+                assert np.array_equal(perm.cpu().numpy(), p_ref)
+        # room for 1000 entries only: status 1, every offset zero, the scatter step writes nothing
+        wsb = L.pcfit_bin2_workspace_bytes(n, S, 0, 1000)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+        F.check(L.pcfit_bin2_count_dev(p(xyz), n, p(dlo), p(dhi), S, F._p(geom), 0, 1000, p(off), p(status), p(ws), wsb,
+                                       st))
+        assert status.item() == 1 and not off.cpu().numpy().any()
+        x = torch.full((16,), 7.0, dtype=torch.float64, device=dev)
+        y = x.clone()
+        F.check(L.pcfit_bin2_scatter_dev(n, S, F._p(geom), 0, 1000, p(off), p(x), p(y), None, p(ws), wsb, st))
+        assert (x == 7.0).all().item() and (y == 7.0).all().item()
+    with pytest.raises(F.PcfitError, match="workspace"):
+        F.check(L.pcfit_bin2_count_dev(p(xyz), n, p(dlo), p(dhi), S, F._p(geom), 0, 0, p(off), p(status), p(ws), 16, st))
+
+
 def test_more_windows_than_one_binning_pass_takes():
     """A long scan cut very finely: 40 000 windows (runs of 16 384 inside the library) - members and order as the
     CPU gives them, through bin_slices, the resident scan's window counts and the analyzer."""
