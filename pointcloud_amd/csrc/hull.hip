@@ -241,11 +241,132 @@ __device__ int chain_finish(const double *px, const double *py, IdxT *list, int 
     return total;
 }
 
+// One pruning round over list[0..L), L <= HULL_PRUNE_PER * threads: every candidate but the two ends stays exactly
+// when the walk from the candidate before it to the one after it turns left at it.  A candidate that goes lies
+// on or above the chord of two points of the set, so it is no vertex of the chain whatever else goes in the same
+// round; a vertex of the chain lies strictly below every such chord and never goes.  Every lane works (a thread
+// holds a run of at most HULL_PRUNE_PER consecutive candidates), the survivors move up in order.  Returns how
+// many stayed.
+constexpr int HULL_PRUNE_PER = 8;
+constexpr int HULL_PRUNE_ROUNDS = 48;
+// CYCLIC: the list is a closed walk (the candidate after the last is the first); the candidates numbered 0 and
+// `top` always stay.
+template <class IdxT, bool CYCLIC = false>
+__device__ __forceinline__ int chain_prune_round(const double *px, const double *py, IdxT *list, int L, int *scratch,
+                                                 int top = 0)
+{
+    const int per = (L + HULL_NT - 1) / HULL_NT;
+    const int b0 = min(L, (int)threadIdx.x * per), b1 = min(L, b0 + per);
+    IdxT mine[HULL_PRUNE_PER];
+    uint32_t keep = 0u;
+    if (b0 < b1) {
+        // the run's candidates and the two around it: one pass, every point loaded once
+        IdxT prev = list[b0 > 0 ? b0 - 1 : (CYCLIC ? L - 1 : 0)];
+        double ax = px[prev], ay = py[prev];
+        IdxT cur = list[b0];
+        double qx = px[cur], qy = py[cur];
+#pragma unroll
+        for (int u = 0; u < HULL_PRUNE_PER; u++) {
+            const int i = b0 + u;
+            if (i < b1) {
+                const IdxT nxt = list[i + 1 < L ? i + 1 : (CYCLIC ? 0 : L - 1)];
+                const double bx = px[nxt], by = py[nxt];
+                bool stay = CYCLIC ? ((int)cur == 0 || (int)cur == top) : (i == 0 || i == L - 1);
+                if (!stay) {
+                    const double l = (qx - ax) * (by - ay), r = (qy - ay) * (bx - ax);
+                    const double det = l - r;
+                    const double bound = 3.3306690738754716e-16 * (fabs(l) + fabs(r));
+                    stay = det > bound ? true : det < -bound ? false : orient_sign(ax, ay, qx, qy, bx, by) > 0;
+                }
+                mine[u] = cur;
+                keep |= stay ? 1u << u : 0u;
+                ax = qx;
+                ay = qy;
+                qx = bx;
+                qy = by;
+                cur = nxt;
+            }
+        }
+    }
+    int total;
+    int at = block_exscan(__popc(keep), scratch, &total);           // (its barriers end all reads of the list)
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++)
+        if (keep >> u & 1u)
+            list[at++] = mine[u];
+    __syncthreads();
+    return total;
+}
+
+// Both chains at once for m sorted points in reach of the pruning rounds (m <= HULL_PRUNE_PER * threads): the
+// points below the line from the first to the last point in ascending order, then those above it in descending
+// order, form one closed walk with the two ends; pruning rounds on it leave the hull, counter-clockwise from the
+// first point - the lower chain followed by the upper one.  Returns the number of vertices at list[0..), or -1
+// when the rounds did not come to an end (the caller then builds the chains one by one).
+template <class IdxT>
+__device__ int hull_by_pruning(const double *px, const double *py, IdxT *list, int m, int *scratch)
+{
+    const double ax = px[0], ay = py[0], bx = px[m - 1], by = py[m - 1];
+    const int per = (m + HULL_NT - 1) / HULL_NT;
+    const int b0 = min(m, (int)threadIdx.x * per), b1 = min(m, b0 + per);
+    uint32_t below = 0u, above = 0u;
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++) {
+        const int i = b0 + u;
+        if (i < b1 && i > 0 && i < m - 1) {
+            const double cx = px[i], cy = py[i];
+            const double l = (bx - ax) * (cy - ay), r = (by - ay) * (cx - ax);
+            const double det = l - r;
+            const double bound = 3.3306690738754716e-16 * (fabs(l) + fabs(r));
+            const int sgn = det > bound ? 1 : det < -bound ? -1 : orient_sign(ax, ay, bx, by, cx, cy);
+            below |= sgn < 0 ? 1u << u : 0u;
+            above |= sgn > 0 ? 1u << u : 0u;
+        }
+    }
+    int total;
+    const int at = block_exscan(__popc(below) | (__popc(above) << 16), scratch, &total);   // (m < 65536)
+    const int n_below = total & 0xffff, n_above = total >> 16;
+    int at_b = 1 + (at & 0xffff), at_a = 1 + n_below + n_above - (at >> 16);
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++) {
+        if (below >> u & 1u)
+            list[at_b++] = (IdxT)(b0 + u);
+        if (above >> u & 1u)
+            list[at_a--] = (IdxT)(b0 + u);
+    }
+    if (threadIdx.x == 0) {
+        list[0] = (IdxT)0;
+        list[1 + n_below] = (IdxT)(m - 1);
+    }
+    __syncthreads();
+    int L = n_below + n_above + 2;
+    for (int round = 0; round < HULL_PRUNE_ROUNDS; round++) {
+        const int left = chain_prune_round<IdxT, true>(px, py, list, L, scratch, m - 1);
+        if (left == L)
+            return L;
+        L = left;
+    }
+    return -1;
+}
+
 // Monotone chain over the candidates list[0..L) -> hull chain at list[0..return)
 template <class IdxT>
 __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, int64_t L, int64_t *pong,
                                 int *scratch)
 {
+    // Pruning rounds first: each costs a handful of instructions per candidate with every lane at work, where a
+    // round of chunks walks 16 candidates per thread one after the other on a few lanes and the finish below
+    // compares every candidate with every other.  A round that takes nothing away has left the chain itself.
+    // Inputs on which the rounds go on and on (each takes at least one candidate) are cut short and go through
+    // the chunks below, which always end.
+    if (L <= (int64_t)HULL_PRUNE_PER * HULL_NT) {
+        for (int round = 0; round < HULL_PRUNE_ROUNDS; round++) {
+            const int left = chain_prune_round<IdxT>(px, py, list, (int)L, scratch);
+            if (left == L)
+                return L;
+            L = left;
+        }
+    }
     constexpr int C0 = 16;
     int64_t c = C0;
     while (true) {
@@ -291,6 +412,115 @@ __device__ int64_t chain_reduce(const double *px, const double *py, IdxT *list, 
             c <<= 1;
         L = total;
     }
+}
+
+// Sort of n points held in LDS (n <= HULL_PRUNE_PER * threads) by (x, y) in a few barriers: a counting sort on a
+// bucket number that never decreases with x, then every bucket put in order by one thread.  The bucket number
+// is uniform in the angle of a ring's points seen from its centre line (their x crowd towards both ends, as
+// 1 / sqrt(t (1 - t)) in t = (x - min) / (max - min)), so buckets of a ring hold a point or two.  Returns false
+// and leaves the points alone when the input does not suit (a coordinate that is not finite, all x equal, a
+// bucket of more than HULL_BUCKET_MAX points as quantised coordinates make them): the caller's sorting network,
+// which takes anything, runs then.  cnt: n_buckets counters.
+constexpr int HULL_BUCKET_MAX = 24;
+__device__ bool bucket_sort_lds(double *px, double *py, int n, uint32_t *cnt, int n_buckets, double *red,
+                                int *scan_scratch)
+{
+    const int tid = threadIdx.x, NT = HULL_NT, lane = tid & 63, wave = tid >> 6, nw = NT >> 6;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    double qx[HULL_PRUNE_PER], qy[HULL_PRUNE_PER];
+    double lo = inf, hi = -inf;
+    bool odd = false;
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++) {
+        const int i = tid + u * NT;
+        qx[u] = qy[u] = 0.0;
+        if (i < n) {
+            qx[u] = px[i];
+            qy[u] = py[i];
+            odd |= !(fabs(qx[u]) < inf) || !(fabs(qy[u]) < inf);
+            lo = fmin(lo, qx[u]);
+            hi = fmax(hi, qx[u]);
+        }
+    }
+    lo = wave_min(lo);
+    hi = wave_max(hi);
+    if (lane == 0) {
+        red[wave] = lo;
+        red[16 + wave] = hi;
+    }
+    for (int b = tid; b < n_buckets; b += NT)
+        cnt[b] = 0u;
+    if (__syncthreads_or(odd))
+        return false;
+    for (int w = 0; w < nw; w++) {
+        lo = fmin(lo, red[w]);
+        hi = fmax(hi, red[16 + w]);
+    }
+    const double range = hi - lo;
+    if (!(range > 0.0) || !(range < inf))
+        return false;                                   // (uniform over the workgroup)
+    const double scale = 1.0 / range, nb = (double)n_buckets;
+    uint32_t bk[HULL_PRUNE_PER], rk[HULL_PRUNE_PER];
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++) {
+        const int i = tid + u * NT;
+        bk[u] = rk[u] = 0u;
+        if (i < n) {
+            const double t = fmin((qx[u] - lo) * scale, 1.0);
+            const double g = t < 0.5 ? sqrt(0.5 * t) : 1.0 - sqrt(0.5 * (1.0 - t));
+            const int b = (int)(g * nb);
+            bk[u] = (uint32_t)(b < n_buckets - 1 ? b : n_buckets - 1);
+            rk[u] = atomicAdd(&cnt[bk[u]], 1u);
+        }
+    }
+    __syncthreads();
+    // first slot of every bucket (a run of buckets per thread), and the fullest bucket
+    const int seg = (n_buckets + NT - 1) / NT;
+    const int b0 = min(n_buckets, tid * seg), b1 = min(n_buckets, b0 + seg);
+    int sum = 0;
+    uint32_t most = 0u;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = cnt[b];
+        sum += (int)c;
+        most = c > most ? c : most;
+    }
+    int total;
+    int at = block_exscan(sum, scan_scratch, &total);
+    if (__syncthreads_or(most > (uint32_t)HULL_BUCKET_MAX))
+        return false;
+    for (int b = b0; b < b1; b++) {
+        const uint32_t c = cnt[b];
+        cnt[b] = (uint32_t)at;
+        at += (int)c;
+    }
+    __syncthreads();
+    // every point sits in a register: into its bucket, in place
+#pragma unroll
+    for (int u = 0; u < HULL_PRUNE_PER; u++) {
+        const int i = tid + u * NT;
+        if (i < n) {
+            const uint32_t d = cnt[bk[u]] + rk[u];
+            px[d] = qx[u];
+            py[d] = qy[u];
+        }
+    }
+    __syncthreads();
+    for (int b = tid; b < n_buckets; b += NT) {
+        const int s0 = (int)cnt[b], s1 = b + 1 < n_buckets ? (int)cnt[b + 1] : n;
+        for (int i = s0 + 1; i < s1; i++) {
+            const double kx = px[i], ky = py[i];
+            int j = i - 1;
+            while (j >= s0 && lex_less(kx, ky, px[j], py[j])) {
+                px[j + 1] = px[j];
+                py[j + 1] = py[j];
+                j--;
+            }
+            px[j + 1] = kx;
+            py[j + 1] = ky;
+        }
+    }
+    __syncthreads();
+    return true;
 }
 
 // ---- the filter for long slices
@@ -595,7 +825,14 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
     int lp = 0;
     while ((1u << lp) < n32 && lp < 31) lp++;
     const uint32_t half = lp > 0 ? (1u << (lp - 1)) : 0u;
-    for (int lk = 1; lk <= lp; lk++) {
+    // (a few hundred points and more in LDS: the counting sort first, where the input suits it; the list's
+    // room, not in use yet, holds its counters)
+    bool sorted = false;
+    if constexpr (IN_LDS) {
+        if (n >= 96 && n <= (int64_t)HULL_PRUNE_PER * HULL_NT && lds_cap >= 256)
+            sorted = bucket_sort_lds(px, py, (int)n, reinterpret_cast<uint32_t *>(list), lds_cap / 2, red, scan_scratch);
+    }
+    for (int lk = 1; lk <= (sorted ? 0 : lp); lk++) {
         for (int ld = lk - 1; ld >= 0; ld--) {
             const uint32_t d = 1u << ld;
             const bool flip = ld == lk - 1;
@@ -699,26 +936,35 @@ __global__ __launch_bounds__(HULL_BLOCK) void unique_hull_kernel(
 
     HULL_MARK(3);
     int64_t *pong = hull_idx + off;
-    // ---- hull: lower chain (left to right), then upper chain (right to left)
-    for (int64_t i = tid; i < m; i += HULL_NT)
-        list[i] = (IdxT)i;
-    __syncthreads();
-    const int64_t hl = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
-    uint32_t *park = wspark + off;                      // the lower chain waits here
-    for (int64_t i = tid; i < hl - 1; i += HULL_NT)
-        park[i] = (uint32_t)list[i];
-    __syncthreads();
-    for (int64_t i = tid; i < m; i += HULL_NT)
-        list[i] = (IdxT)(m - 1 - i);
-    __syncthreads();
-    const int64_t hu = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
+    uint32_t *park = wspark + off;
+    int64_t h = -1;
+    if (m <= (int64_t)HULL_PRUNE_PER * HULL_NT && m < 65536) {
+        // ---- hull: both chains at once
+        h = hull_by_pruning<IdxT>(px, py, list, (int)m, scan_scratch);
+        for (int64_t i = tid; i < h; i += HULL_NT)
+            pong[i] = (int64_t)list[i];
+    }
+    if (h < 0) {
+        // ---- hull: lower chain (left to right), then upper chain (right to left)
+        for (int64_t i = tid; i < m; i += HULL_NT)
+            list[i] = (IdxT)i;
+        __syncthreads();
+        const int64_t hl = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
+        for (int64_t i = tid; i < hl - 1; i += HULL_NT)     // the lower chain waits in park
+            park[i] = (uint32_t)list[i];
+        __syncthreads();
+        for (int64_t i = tid; i < m; i += HULL_NT)
+            list[i] = (IdxT)(m - 1 - i);
+        __syncthreads();
+        const int64_t hu = chain_reduce<IdxT>(px, py, list, m, pong, scan_scratch);
+        h = (hl - 1) + (hu - 1);
+        // both chains end on the other's first vertex: drop each chain's last entry
+        for (int64_t i = tid; i < hl - 1; i += HULL_NT)
+            pong[i] = (int64_t)park[i];
+        for (int64_t i = tid; i < hu - 1; i += HULL_NT)
+            pong[hl - 1 + i] = (int64_t)list[i];
+    }
     HULL_MARK(4);
-    const int64_t h = (hl - 1) + (hu - 1);
-    // both chains end on the other's first vertex: drop each chain's last entry
-    for (int64_t i = tid; i < hl - 1; i += HULL_NT)
-        pong[i] = (int64_t)park[i];
-    for (int64_t i = tid; i < hu - 1; i += HULL_NT)
-        pong[hl - 1 + i] = (int64_t)list[i];
     if (tid == 0) {
         n_hull[s] = h;
         found_at = 0x7fffffff;

@@ -1300,3 +1300,35 @@ def test_last_accepted_step_taken_without_its_sweep():
         assert rel(fit[s], want) < 1e-9, (s, modelled[s], fit[s], want)
         same_counts += (iters[s, 0], iters[s, 1]) == (it, acc)
     assert same_counts >= 0.97 * len(sets)
+
+
+def test_hull_sort_and_chain_paths_and_their_fall_backs():
+    """Slices held in LDS, a few hundred to a few thousand points: rings (counting sort on x, both chains by pruning
+    rounds), coordinates on a coarse grid and a vertical bar (buckets too full / all x equal: the sorting network),
+    a cascade in which each pruning round can take one candidate only (more rounds than are tried: the chains are
+    built one by one), few distinct points, and collinear points.  Distinct points and hull as the CPU gives them."""
+    gen = np.random.default_rng(77)
+    sets = []
+    for n in (300, 1784, 5000, 8192):
+        th = gen.uniform(0, 2 * np.pi, n)
+        rr = 10.0 + gen.normal(0, 0.05, n)
+        sets.append(np.stack([3 + rr * np.cos(th), -2 + rr * np.sin(th)], 1))
+    grid = np.round(sets[2] * 2.0) / 2.0                                   # 40 x 40 distinct positions
+    bar = np.stack([np.full(700, 1.25), gen.normal(0, 1, 700)], 1)
+    bar[::7, 0] = 1.5
+    k = np.arange(400.0)
+    cascade = np.concatenate([np.stack([k, k * k], 1), [[400.0, -1e9]], [[200.0, 5e5]]])
+    few = sets[0][gen.integers(0, 5, 600)]
+    line = np.stack([k, 2.0 * k + 1.0], 1)
+    sets += [grid, bar, cascade, few, line]
+    x, y, off = csr(sets)
+    h = F.unique_hull_batch(x, y, off)
+    for s, xy in enumerate(sets):
+        uniq = R.unique_rows(xy)
+        o, nu, nh = off[s], int(h["n_unique"][s]), int(h["n_hull"][s])
+        assert nu == len(uniq) and np.array_equal(np.stack([h["ux"][o:o + nu], h["uy"][o:o + nu]], 1), uniq), s
+        if s == len(sets) - 1:
+            assert h["status"][s] != 0                                      # rank deficient: no hull asked of it
+            continue
+        assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
+    assert int(h["n_hull"][6]) <= 5                                         # the cascade: next to nothing is left of it

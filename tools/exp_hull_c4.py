@@ -12,7 +12,7 @@ L = F.lib()
 if PH:
     L.pcfit_debug_hull_phases.argtypes = [C.c_void_p, C.c_int]
 for S, n in ((int(sys.argv[1]), int(sys.argv[2])),) if len(sys.argv) > 2 else ((600, 50000), (57, 50000)):
-    x, y, off = make_slices(S, n, seed=5, outlier_frac=0.1)
+    x, y, off = make_slices(S, n, seed=5, outlier_frac=float(os.environ.get("OUTL", 0.1)))
     run = lambda: F.hybrid_batch(x, y, off, max_trials=16, want_unique=False, want_profile=False)
     h = run()
     out = np.zeros(8, np.int64)
