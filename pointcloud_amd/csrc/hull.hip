@@ -569,8 +569,12 @@ __global__ __launch_bounds__(SPLIT_BLOCK) void hull_filter_kernel(const double *
     if (offsets[r.slice + 1] - off <= lds_cap)
         return;
     if constexpr (PASS == 0) {
+        // (the centre the sectors are laid about has to lie inside the hull and no more: the mean of the first
+        // eighth of every segment, at least 1024 points of it, serves as well as the mean of all)
+        SegRef q = r;
+        q.n = min(r.n, max(1024, r.n / 8));
         double s1[2] = {0.0, 0.0};
-        segment_points(r, [&](double px, double py, int32_t, bool valid) {
+        segment_points(q, [&](double px, double py, int32_t, bool valid) {
             s1[0] += valid ? px : 0.0;
             s1[1] += valid ? py : 0.0;
         });
@@ -578,6 +582,7 @@ __global__ __launch_bounds__(SPLIT_BLOCK) void hull_filter_kernel(const double *
         if (threadIdx.x == 0) {
             part[r.seg * SPLIT_PART] = s1[0];
             part[r.seg * SPLIT_PART + 1] = s1[1];
+            part[r.seg * SPLIT_PART + 2] = (double)q.n;
         }
     } else if constexpr (PASS == 1) {
         for (int j = threadIdx.x; j < HULL_SECTORS; j += SPLIT_BLOCK)
@@ -641,19 +646,21 @@ __global__ __launch_bounds__(WAVE) void hull_filter_slice_kernel(const int64_t *
         return;
     }
     if constexpr (STEP == 0) {
-        double v[2] = {0.0, 0.0};
+        double v[3] = {0.0, 0.0, 0.0};
         const int64_t seg0 = segstart[s], nseg = segstart[s + 1] - seg0;
         for (int64_t j = threadIdx.x; j < nseg; j += WAVE) {
             v[0] += part[(seg0 + j) * SPLIT_PART];
             v[1] += part[(seg0 + j) * SPLIT_PART + 1];
+            v[2] += part[(seg0 + j) * SPLIT_PART + 2];
         }
         v[0] = wave_sum(v[0]);
         v[1] = wave_sum(v[1]);
+        v[2] = wave_sum(v[2]);
         for (int j = threadIdx.x; j < HULL_SECTORS; j += WAVE)
             a.sect[j] = 0ull;
         if (threadIdx.x == 0) {
-            a.cx = v[0] / (double)n;
-            a.cy = v[1] / (double)n;
+            a.cx = v[0] / v[2];
+            a.cy = v[1] / v[2];
             a.filtered = 1;
             a.kept = 0ull;
             a.sectors = n >= 200000 ? HULL_SECTORS : (n >= 60000 ? HULL_SECTORS / 2 : HULL_SECTORS / 4);
