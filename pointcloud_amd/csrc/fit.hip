@@ -341,8 +341,11 @@ __device__ __forceinline__ void each_point(const View &P, F &&f)
 
 // Static LDS of a fit kernel, in doubles: two scratch areas for the workgroup
 // reductions (17 values x 16 waves each, used alternately) and two areas for
-// totals (12 sums, the smallest and the largest distance, three model sums).
-constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SIZE = RED_TOT + 2 * RED_AREA;
+// totals (12 sums, the smallest and the largest distance, three model sums), and 16 doubles through which the
+// first wave hands the others what it has worked out alone (the Kasa circle; the LM loop's next candidate, in
+// the end its result).
+constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE = RED_TOT + 2 * RED_AREA,
+              RED_SIZE = RED_SHARE + 16;
 
 // Where the next reduction of a workgroup puts its partial sums.  Alternating
 // between two scratch areas (and never writing totals that may still be read)
@@ -352,6 +355,7 @@ struct RedCtx {
     int count;
     __device__ __forceinline__ double *scratch() { return lds + (count++ & 1) * RED_SCR; }
     __device__ __forceinline__ double *totals(int which) { return lds + RED_TOT + RED_AREA * which; }
+    __device__ __forceinline__ double *share() { return lds + RED_SHARE; }
 };
 
 // circle_fitting.py:35-54.  Uniform result in every thread.
@@ -414,7 +418,24 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
         m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
         m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
     }
-    return kasa_from_moments(m, mx, my, n, out);
+    // The circle from the moments (divisions, a square root: some 250 instructions) is the same in every thread.
+    // The first wave works it out and the others take it from LDS: their SIMDs are free for the workgroup
+    // next door meanwhile.
+    double *share = red.share();
+    if (threadIdx.x < WAVE) {
+        const int st = kasa_from_moments(m, mx, my, n, out);
+        if (threadIdx.x == 0) {
+            share[0] = out[0];
+            share[1] = out[1];
+            share[2] = out[2];
+            share[3] = (double)st;
+        }
+    }
+    __syncthreads();
+    out[0] = share[0];
+    out[1] = share[1];
+    out[2] = share[2];
+    return (int)share[3];
 }
 
 // circle_fitting.py:80-109.  Every accept / reject decision is the reference's
@@ -532,20 +553,68 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     };
 
     // (one call site for the sweep: its body is the bulk of the kernel's code)
+    // The loop between the sweeps - 3x3 solves, the stopping rules, the model of the last step: several hundred
+    // instructions on values every thread would hold alike - runs on the first wave only.  The others wait at
+    // the barrier for the next candidate (in the end: for the result), their SIMDs free for the workgroup next
+    // door.
     LmState st;
     lm_begin(st, par, prm);
-    while (!st.done) {
-        const int into = lm_into(st);
-        sweep(st.tx, st.ty, st.tr, red.totals(into));
-        lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
+    if (st.done) {                                  // (max_iter <= 0: the start is the result)
+        lm_finish(st, par, iters);
+        reach[0] = reach[1] = 0.0;
+        return false;
     }
-    lm_finish(st, par, iters);
+    double *share = red.share();
+    int32_t *ishare = reinterpret_cast<int32_t *>(share + 10);
+    double tx = st.tx, ty = st.ty, tr = st.tr;
+    int into = 0;
+    bool done = false;
+    while (!done) {
+        sweep(tx, ty, tr, red.totals(into));
+        if (threadIdx.x < WAVE) {
+            lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
+            if (threadIdx.x == 0) {
+                share[0] = st.tx;
+                share[1] = st.ty;
+                share[2] = st.tr;
+                ishare[0] = lm_into(st);
+                ishare[1] = st.done ? 1 : 0;
+                if (st.done) {
+                    share[3] = st.cx;
+                    share[4] = st.cy;
+                    share[5] = st.rad;
+                    share[6] = st.min_ri;
+                    share[7] = st.max_ri;
+                    int32_t r4[4];
+                    double unused[3];
+                    lm_finish(st, unused, r4);
+                    ishare[2] = r4[0];
+                    ishare[3] = r4[1];
+                    ishare[4] = r4[2];
+                    ishare[5] = r4[3];
+                    ishare[6] = st.cur >= 0 ? 1 : 0;
+                }
+            }
+        }
+        __syncthreads();
+        tx = share[0];
+        ty = share[1];
+        tr = share[2];
+        into = ishare[0];
+        done = ishare[1] != 0;
+    }
+    par[0] = share[3];
+    par[1] = share[4];
+    par[2] = share[5];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        iters[k] = ishare[2 + k];
     ph.mark(4);
     // bounds of the smallest (from above) and the largest (from below) distance (sqrt + 1e-16) of the slice's points
     // from the returned centre: known when a sweep ran at these parameters or one modelled step before them
-    reach[0] = st.min_ri;
-    reach[1] = st.max_ri;
-    return st.cur >= 0;
+    reach[0] = share[6];
+    reach[1] = share[7];
+    return ishare[6] != 0;
 }
 
 template <int PT_R, int PT_L, int FIT_BLOCK>

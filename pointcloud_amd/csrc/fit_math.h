@@ -191,6 +191,11 @@ __device__ __forceinline__ int lm_into(const LmState &st) { return st.cur == 0 ?
 //    F(p + d + s) >= F(p + d) + g'.s - |s_c|^2 sum |r_i| / rho_i
 // (convexity, as in lm_step) shows that none of them gains a quarter of tol_cost: all are rejected.
 // `slack`: how far the centre moves (the distances at p + d lie within that of those at p).
+// (every quantity below is a bound, so square roots and quotients are taken from the hardware's reciprocal and
+// reciprocal square root and widened by more than their error - a correctly rounded division or square root is
+// a chain of some 25 dependent instructions, and a dozen of them sat between the last sweep and the residual pass)
+__device__ __forceinline__ double sqrt_above(double v) { return v * __builtin_amdgcn_rsq(v + 1e-300) * (1.0 + 1e-6); }
+__device__ __forceinline__ double rcp_above(double v) { return rcp_nr(v) * (1.0 + 1e-9); }       // v > 0
 __device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const LmParams &prm, const double *hg,
                                                       double &slack)
 {
@@ -198,19 +203,20 @@ __device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const L
     const double H00 = hg[0], H01 = hg[1], H02 = hg[2], H11 = hg[3], H12 = hg[4], H22 = hg[5];
     const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
     const double n = H22, lo = hg[12], hi = hg[13], R = st.rad, F = st.prev;
-    const double dc2 = d0 * d0 + d1 * d1, dc = sqrt(dc2), move = dc + fabs(d2);
+    const double dc2 = d0 * d0 + d1 * d1, dc = sqrt_above(dc2), move = dc + fabs(d2);
     const double amax = fmax(hi - R, R - lo);
     // all points stay regular over this step and another no longer than it; distances stay above rho
     const double rho = lo - 2.0 * dc;
     if (!(amax + 3.0 * move <= prm.delta && 16.0 * dc <= lo && R + d2 > 1e-12 && n >= 3.0 && F >= 0.0))
         return false;
+    const double inv_rho = rcp_above(rho);
     const double B00 = hg[16] - hg[14], B01 = -hg[15], B11 = hg[14];
     const double Hd0 = H00 * d0 + H01 * d1 + H02 * d2, Hd1 = H01 * d0 + H11 * d1 + H12 * d2,
                  Hd2 = H02 * d0 + H12 * d1 + H22 * d2;
     const double Bd0 = B00 * d0 + B01 * d1, Bd1 = B01 * d0 + B11 * d1;
-    const double s1 = sqrt(2.0 * n * F) + 3.0 * n * move;       // sum |r_i| anywhere near (Cauchy-Schwarz at p)
-    const double L3 = (4.25 * n + 3.0 * s1 / rho) / rho;
-    const double dn2 = dc2 + d2 * d2, dn = sqrt(dn2);
+    const double s1 = sqrt_above(2.0 * n * F) + 3.0 * n * move;  // sum |r_i| anywhere near (Cauchy-Schwarz at p)
+    const double L3 = (4.25 * n + 3.0 * s1 * inv_rho) * inv_rho;
+    const double dn2 = dc2 + d2 * d2, dn = sqrt_above(dn2);
     const double Ef = L3 * dn2 * dn * (1.0 / 6.0), Eg = 0.5 * L3 * dn2;
     const double dF = (g0 * d0 + g1 * d1 + g2 * d2) + 0.5 * (d0 * Hd0 + d1 * Hd1 + d2 * Hd2) +
                       0.5 * (d0 * Bd0 + d1 * Bd1) + Ef;
@@ -223,18 +229,20 @@ __device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const L
     if (!solve3x3(A, b, y))
         return false;
     const double a = gh[0] * y[0] + gh[1] * y[1] + gh[2] * y[2];                    // gh.H^-1 gh
-    const double yn = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
-    const double gn = sqrt(gh[0] * gh[0] + gh[1] * gh[1] + gh[2] * gh[2]);
+    const double yn = sqrt_above(y[0] * y[0] + y[1] * y[1] + y[2] * y[2]);
+    const double gn = sqrt_above(gh[0] * gh[0] + gh[1] * gh[1] + gh[2] * gh[2]);
     // the smallest eigenvalue of H from below: the other two have a product of at most (trace / 2)^2
     const double det = H00 * (H11 * H22 - H12 * H12) - H01 * (H01 * H22 - H12 * H02) + H02 * (H01 * H12 - H11 * H02);
     const double ht = 0.5 * (H00 + H11 + H22);
-    const double lmin = det / (ht * ht);
-    const double dH = 12.0 * n * dc / rho;           // each j j^T moves by at most 2 sqrt2 * 2 (2 dc) / rho
+    if (!(det > 0.0 && ht > 0.0))
+        return false;
+    const double lmin = det * rcp_nr(ht * ht) * (1.0 - 1e-9);
+    const double dH = 12.0 * n * dc * inv_rho;       // each j j^T moves by at most 2 sqrt2 * 2 (2 dc) / rho
     if (!(a >= 0.0 && lmin > 2.0 * dH))
         return false;
-    const double lm2 = lmin - dH, kap = 1.0 + dH / lm2;
-    const double sn = (gn + Eg) / lm2;                // no later step is longer
-    const double val = kap * (a + 2.0 * yn * Eg + Eg * Eg / lmin) + sn * sn * (s1 / rho);
+    const double inv_lm2 = rcp_above(lmin - dH), kap = 1.0 + dH * inv_lm2;
+    const double sn = (gn + Eg) * inv_lm2;            // no later step is longer
+    const double val = kap * (a + 2.0 * yn * Eg + Eg * Eg * rcp_above(lmin)) + sn * sn * (s1 * inv_rho);
     if (!(val < 0.25 * prm.tol_cost && sn <= dc && 2.0 * sn <= rho))
         return false;
     slack = dc;
