@@ -366,8 +366,9 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     if (P.n < 3)
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
+    const bool lead = threadIdx.x < WAVE;
     double m[7];   // suu svv suv suuu svvv suvv svuu, about the mean
-    double mx, my;
+    double mx = 0.0, my = 0.0;
     if constexpr (View::STREAM) {
         double s1[2] = {0.0, 0.0};
         each_point(P, [&](double px, double py, int32_t, bool valid) {
@@ -393,10 +394,12 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
             m[6] = fma(v, uu, m[6]);
         });
         tot = red.totals(1);
-        block_reduce_to_lds<7, false, NW>(m, 0.0, red.scratch(), tot);
+        block_reduce_to_lds<7, false, NW, false>(m, 0.0, red.scratch(), tot);
+        if (lead) {
 #pragma unroll
-        for (int k = 0; k < 7; k++)
-            m[k] = tot[k];
+            for (int k = 0; k < 7; k++)
+                m[k] = tot[k];
+        }
     } else {
         // the power sums about the slice's first point came with the loads: one reduction, then the
         // moments about the mean by the binomial identities (a, b = the mean, seen from the first point)
@@ -405,24 +408,26 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
         for (int k = 0; k < 9; k++)
             q[k] = P.m9[k];
         double *tot = red.totals(1);
-        block_reduce_to_lds<9, false, NW>(q, 0.0, red.scratch(), tot);
-        const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
-        const double a = su / n, b = sv / n;
-        mx = P.x0 + a;
-        my = P.y0 + b;
-        m[0] = suu - a * su;
-        m[1] = svv - b * sv;
-        m[2] = suv - a * sv;
-        m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
-        m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
-        m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
-        m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
+        block_reduce_to_lds<9, false, NW, false>(q, 0.0, red.scratch(), tot);
+        if (lead) {
+            const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
+            const double a = su / n, b = sv / n;
+            mx = P.x0 + a;
+            my = P.y0 + b;
+            m[0] = suu - a * su;
+            m[1] = svv - b * sv;
+            m[2] = suv - a * sv;
+            m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
+            m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
+            m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
+            m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
+        }
     }
     // The circle from the moments (divisions, a square root: some 250 instructions) is the same in every thread.
-    // The first wave works it out and the others take it from LDS: their SIMDs are free for the workgroup
-    // next door meanwhile.
+    // The first wave - whose lanes have just written the totals, so it need not wait for anyone - works it out
+    // and the others take it from LDS: their SIMDs are free for the workgroup next door meanwhile.
     double *share = red.share();
-    if (threadIdx.x < WAVE) {
+    if (lead) {
         const int st = kasa_from_moments(m, mx, my, n, out);
         if (threadIdx.x == 0) {
             share[0] = out[0];
@@ -477,7 +482,8 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     // whether any point was not regular.  The general one handles all points with selects.  For a
     // regular point both give the same bits.  A sweep runs the short form over the full groups (and
     // the general one over the ragged group); when a point turns out not to be regular the sweep
-    // is run again in the general form, and so are all later sweeps of this slice.
+    // is run again in the general form, and so are all later sweeps of this slice.  The totals are
+    // left for the first wave to read (no barrier after they are written).
     bool general = false;
     auto sweep = [&](double px0, double py0, double pr, double *tot) {
         constexpr int U = View::GROUP;
@@ -534,11 +540,9 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);
-            block_reduce_to_lds2<15, NW, 12>(acc, low, high, red.scratch(), tot);
+            block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot);
             ph.mark(3);
-            if (tot[12] != -inf)
-                return;
-            general = true;             // (every thread has read tot[12] before the barrier inside the next reduction)
+            return;
         }
 #pragma unroll
         for (int k = 0; k < 15; k++)
@@ -548,7 +552,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false); });
         P.ragged_group(ragged);
         ph.mark(2);
-        block_reduce_to_lds2<15, NW, 12>(acc, low, high, red.scratch(), tot);
+        block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot);
         ph.mark(3);
     };
 
@@ -572,8 +576,12 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     while (!done) {
         sweep(tx, ty, tr, red.totals(into));
         if (threadIdx.x < WAVE) {
-            lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
+            // (a short-form sweep that met a point it is not made for says so in place of the smallest distance)
+            const bool again = !general && red.totals(into)[12] == -inf;
+            if (!again)
+                lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
             if (threadIdx.x == 0) {
+                ishare[7] = again ? 1 : 0;
                 share[0] = st.tx;
                 share[1] = st.ty;
                 share[2] = st.tr;
@@ -597,6 +605,10 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             }
         }
         __syncthreads();
+        if (ishare[7]) {
+            general = true;                         // the same sweep once more, in the general form
+            continue;                               // (the word is written again only after the sweep's barrier)
+        }
         tx = share[0];
         ty = share[1];
         tr = share[2];

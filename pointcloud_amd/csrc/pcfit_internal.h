@@ -428,8 +428,11 @@ __device__ __forceinline__ double wave_min(double v)
 // in LDS for every thread to read after the call.  scratch: (K + 1) * 16 doubles.
 // Order: reduce-scatter butterfly inside a wave, then waves 0, 1, 2, ...
 // Two barriers; the caller alternates between two scratch areas (and makes sure
-// nobody still reads dst), so that none is needed on entry.
-template <int K, bool WITH_MIN, int NW>
+// nobody still reads dst), so that none is needed on entry.  Without END_BARRIER the
+// second one is left out: the totals are written by lanes of the first wave, which
+// may read them at once (LDS operations of one wave complete in order); any other
+// wave has to pass a barrier of the caller's first.
+template <int K, bool WITH_MIN, int NW, bool END_BARRIER = true>
 __device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, double *scratch, double *dst)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -460,7 +463,8 @@ __device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, 
             s = fmin(s, scratch[K * 16 + w]);
         dst[K] = s;
     }
-    __syncthreads();
+    if constexpr (END_BARRIER)
+        __syncthreads();
 }
 
 __device__ __forceinline__ double wave_max(double v)
@@ -470,7 +474,7 @@ __device__ __forceinline__ double wave_max(double v)
 
 // The same with two extremes: the smallest `low` at dst[AT] and the largest `high` at dst[AT + 1]; the sums
 // from the AT-th on follow them (sum k at dst[k + 2]).  scratch: (K + 2) * 16 doubles.
-template <int K, int NW, int AT = K>
+template <int K, int NW, int AT = K, bool END_BARRIER = true>
 __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low, double high, double *scratch,
                                                      double *dst)
 {
@@ -510,7 +514,8 @@ __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low,
             s = fmax(s, scratch[(K + 1) * 16 + w]);
         dst[AT + 1] = s;
     }
-    __syncthreads();
+    if constexpr (END_BARRIER)
+        __syncthreads();
 }
 
 // (theta, r) as the reference forms them: theta = (atan2(dy,dx) + 2pi) mod 2pi
