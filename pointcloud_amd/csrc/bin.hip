@@ -15,8 +15,11 @@
 //            ordering: stable and deterministic by construction.  For up to
 //            256 windows the points go through LDS first (see
 //            bin_scatter_staged_kernel) so that the output is written in runs;
-//            the host-level calls bin more windows than that in two levels
-//            when the scan is large (bin_two_level).
+//            more windows than that are binned in two levels when the scan is
+//            large (bin_two_level for the host-level calls, pcfit_bin2_*_dev
+//            for callers on the device): first into groups of 64 or 128
+//            windows with a 16-bit key per entry, then every group into its
+//            windows by the keys, both through the staged kernel.
 //
 // Windows are closed intervals that may share an edge, so a point can belong
 // to two consecutive windows (both get a copy) or to none.  Membership is
@@ -24,7 +27,8 @@
 // spacing is used only to find the candidate window and to skip the array
 // look-ups for points that are clearly interior.
 // HBM traffic: 24 B/point read in count, 24 B read + 16 B (+8 B perm) written
-// in scatter.
+// in scatter; in two levels 24 B (count) + 24 B read + 18 B written (level 1)
+// + 2 B (count) + 18 B read + 16 B written (level 2), +16 B with perm.
 #include <stdlib.h>
 
 #include <algorithm>

@@ -3,31 +3,41 @@
 // gfx950.
 //
 //   sort     the slice's (x, y) pairs lexicographically (what np.unique(axis=0)
-//            does) with an ascending-only bitonic network; slots past the end
-//            count as +inf and are never stored;
+//            does).  In LDS, from 96 points on: a counting sort on a bucket
+//            number that never decreases with x, every bucket then put in
+//            order by one thread (bucket_sort_lds).  Otherwise, and for inputs
+//            that do not suit the buckets: an ascending-only bitonic network;
+//            slots past the end count as +inf and are never stored;
 //   unique   neighbours that compare equal are dropped by a prefix-sum
 //            compaction;
 //   rank     singular values of the centred cloud as root sums of squares of
 //            its projections on the principal axes of the 2x2 scatter matrix;
-//   hull     Andrew's monotone chain, cut into chunks: every thread runs the
-//            chain on its own run of 16+ consecutive candidates, survivors are
-//            compacted, and the rounds repeat (chunks double when a round
-//            removes less than half) until one thread finishes the rest.  The
-//            orientation test is exact (floating-point filter, then an
-//            expansion sum), so the vertex set does not depend on how the
-//            chunks fall and equals the serial chain's.
+//   hull     the sorted points below the line from the first to the last one,
+//            ascending, then those above it, descending, form a closed walk;
+//            rounds in which every candidate at which the walk does not turn
+//            left is dropped, all at once, leave the counter-clockwise hull
+//            from the lexicographic minimum (hull_by_pruning).  Where those
+//            rounds do not end in time, and in global memory: Andrew's monotone
+//            chain, cut into chunks: every thread runs the chain on its own run
+//            of 16+ consecutive candidates, survivors are compacted, and the
+//            rounds repeat (chunks double when a round removes less than half)
+//            until one thread finishes the rest.  The orientation test is exact
+//            (floating-point filter, then an expansion sum), so the vertex set
+//            does not depend on how the rounds or chunks fall and equals the
+//            serial chain's.
 //
 // A slice of up to 8192 points is sorted and hulled inside the 160 KB LDS
 // (16 B of coordinates + 2 B of index per point); longer slices run the same
 // code on a global-memory workspace - after a filter that drops the points
-// which cannot be hull vertices: around the slice's centroid c the plane is cut
+// which cannot be hull vertices: around a centre c inside the hull (the mean
+// of a part of the slice's points) the plane is cut
 // into K sectors (128..512 by slice length) and the farthest point of every
 // sector is found.  A point of sector j lies between the farthest points A, B
 // of the two flanking sectors as seen from c, at most 24/K rad apart, and the
 // segment AB stays farther from c than min(|cA|, |cB|) cos(12/K): a point closer
 // than that is inside the triangle cAB, hence no hull vertex (details at
 // hull_filter_slice_kernel).  The threshold follows the outline sector by
-// sector, so it does not matter where inside the outline the centroid lies.
+// sector, so it does not matter where inside the outline the centre lies.
 // For a noisy ring that leaves a few percent of the points.  The filter runs
 // one workgroup per 8192 points; what it keeps is then sorted, made unique and
 // hulled as before, so hull vertices and their order are unchanged.  A caller
