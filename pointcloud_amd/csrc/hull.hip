@@ -673,7 +673,7 @@ __global__ __launch_bounds__(WAVE) void hull_filter_slice_kernel(const int64_t *
             a.cy = v[1] / v[2];
             a.filtered = 1;
             a.kept = 0ull;
-            a.sectors = n >= 200000 ? HULL_SECTORS : (n >= 60000 ? HULL_SECTORS / 2 : HULL_SECTORS / 4);
+            a.sectors = n >= 32768 ? HULL_SECTORS : (n >= 16384 ? HULL_SECTORS / 2 : HULL_SECTORS / 4);
         }
     } else {
         const int K = (int)a.sectors;
