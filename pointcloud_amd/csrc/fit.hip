@@ -196,14 +196,34 @@ struct SliceView {
     {
         constexpr int U = GROUP;
         if constexpr (STREAM) {
-            for (int32_t first = 0; first + U * FIT_BLOCK <= n; first += U * FIT_BLOCK) {
-                double px[U], py[U];
+            // the loads of the two trips after the current one are in flight while it is worked on: one trip's
+            // arithmetic is far shorter than a trip to HBM.  Three sets of registers take turns (a loop of three
+            // trips, so that no set has to be copied into another, which would wait for its loads).
+            const int32_t trips = n / (U * FIT_BLOCK);
+            double ax[U], ay[U], bx[U], by[U], cx[U], cy[U];
+            if (trips == 0)
+                return;
+            // (every fetch is issued whatever t: past the end it reads the last trip again.  A load behind a
+            // branch leaves the compiler unsure how many are in flight, and it then waits for all of them.)
+            auto fetch = [&](double (&qx)[U], double (&qy)[U], int32_t t) {
+                const int32_t at = (t < trips ? t : trips - 1) * (U * FIT_BLOCK) + (int32_t)threadIdx.x;
 #pragma unroll
                 for (int u = 0; u < U; u++) {
-                    px[u] = xs[first + u * FIT_BLOCK + threadIdx.x];
-                    py[u] = ys[first + u * FIT_BLOCK + threadIdx.x];
+                    qx[u] = xs[at + u * FIT_BLOCK];
+                    qy[u] = ys[at + u * FIT_BLOCK];
                 }
-                fg(px, py, first + (int32_t)threadIdx.x);
+            };
+            fetch(ax, ay, 0);
+            fetch(bx, by, 1);
+            for (int32_t t = 0; t < trips; t += 3) {
+                fetch(cx, cy, t + 2);
+                fg(ax, ay, t * (U * FIT_BLOCK) + (int32_t)threadIdx.x);
+                fetch(ax, ay, t + 3);
+                if (t + 1 < trips)
+                    fg(bx, by, (t + 1) * (U * FIT_BLOCK) + (int32_t)threadIdx.x);
+                fetch(bx, by, t + 4);
+                if (t + 2 < trips)
+                    fg(cx, cy, (t + 2) * (U * FIT_BLOCK) + (int32_t)threadIdx.x);
             }
         } else {
 #pragma unroll
@@ -369,59 +389,47 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     const bool lead = threadIdx.x < WAVE;
     double m[7];   // suu svv suv suuu svvv suvv svuu, about the mean
     double mx = 0.0, my = 0.0;
+    // the power sums about the slice's first point: they came with the loads, or (a slice that is streamed) a
+    // pass over the points takes them; one reduction, then the moments about the mean by the binomial
+    // identities (a, b = the mean, seen from the first point)
+    double q[9];
     if constexpr (View::STREAM) {
-        double s1[2] = {0.0, 0.0};
-        each_point(P, [&](double px, double py, int32_t, bool valid) {
-            s1[0] += valid ? px : 0.0;
-            s1[1] += valid ? py : 0.0;
-        });
-        double *tot = red.totals(0);
-        block_reduce_to_lds<2, false, NW>(s1, 0.0, red.scratch(), tot);
-        mx = tot[0] / n;
-        my = tot[1] / n;
 #pragma unroll
-        for (int k = 0; k < 7; k++)
-            m[k] = 0.0;
+        for (int k = 0; k < 9; k++)
+            q[k] = 0.0;
+        const double x0 = P.x0, y0 = P.y0;
         each_point(P, [&](double px, double py, int32_t, bool valid) {
-            const double u = valid ? px - mx : 0.0, v = valid ? py - my : 0.0;
+            const double u = valid ? px - x0 : 0.0, v = valid ? py - y0 : 0.0;
             const double uu = u * u, vv = v * v;
-            m[0] += uu;
-            m[1] += vv;
-            m[2] = fma(u, v, m[2]);
-            m[3] = fma(uu, u, m[3]);
-            m[4] = fma(vv, v, m[4]);
-            m[5] = fma(u, vv, m[5]);
-            m[6] = fma(v, uu, m[6]);
+            q[0] += u;
+            q[1] += v;
+            q[2] += uu;
+            q[3] += vv;
+            q[4] = fma(u, v, q[4]);
+            q[5] = fma(uu, u, q[5]);
+            q[6] = fma(vv, v, q[6]);
+            q[7] = fma(u, vv, q[7]);
+            q[8] = fma(v, uu, q[8]);
         });
-        tot = red.totals(1);
-        block_reduce_to_lds<7, false, NW, false>(m, 0.0, red.scratch(), tot);
-        if (lead) {
-#pragma unroll
-            for (int k = 0; k < 7; k++)
-                m[k] = tot[k];
-        }
     } else {
-        // the power sums about the slice's first point came with the loads: one reduction, then the
-        // moments about the mean by the binomial identities (a, b = the mean, seen from the first point)
-        double q[9];
 #pragma unroll
         for (int k = 0; k < 9; k++)
             q[k] = P.m9[k];
-        double *tot = red.totals(1);
-        block_reduce_to_lds<9, false, NW, false>(q, 0.0, red.scratch(), tot);
-        if (lead) {
-            const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
-            const double a = su / n, b = sv / n;
-            mx = P.x0 + a;
-            my = P.y0 + b;
-            m[0] = suu - a * su;
-            m[1] = svv - b * sv;
-            m[2] = suv - a * sv;
-            m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
-            m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
-            m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
-            m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
-        }
+    }
+    double *tot = red.totals(1);
+    block_reduce_to_lds<9, false, NW, false>(q, 0.0, red.scratch(), tot);
+    if (lead) {
+        const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
+        const double a = su / n, b = sv / n;
+        mx = P.x0 + a;
+        my = P.y0 + b;
+        m[0] = suu - a * su;
+        m[1] = svv - b * sv;
+        m[2] = suv - a * sv;
+        m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
+        m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
+        m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
+        m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
     }
     // The circle from the moments (divisions, a square root: some 250 instructions) is the same in every thread.
     // The first wave - whose lanes have just written the totals, so it need not wait for anyone - works it out

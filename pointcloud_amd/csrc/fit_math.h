@@ -220,7 +220,9 @@ __device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const L
     const double Ef = L3 * dn2 * dn * (1.0 / 6.0), Eg = 0.5 * L3 * dn2;
     const double dF = (g0 * d0 + g1 * d1 + g2 * d2) + 0.5 * (d0 * Hd0 + d1 * Hd1 + d2 * Hd2) +
                       0.5 * (d0 * Bd0 + d1 * Bd1) + Ef;
-    if (!(dF < -(prm.tol_cost + 2e-15 * n * F)))
+    // (the rounding of a cost summed over n / 256 terms per thread, then by tree, and of the reference's pairwise
+    // sum over blocks of 128: at most (n / 256 + 200) roundings of F each way)
+    if (!(dF < -(prm.tol_cost + 4.4e-16 * (n * (1.0 / 256.0) + 200.0) * F)))
         return false;
     // the gradient at p + d, to within Eg
     const double gh[3] = {g0 + Hd0 + Bd0, g1 + Hd1 + Bd1, g2 + Hd2};
@@ -240,13 +242,53 @@ __device__ __forceinline__ bool lm_model_step_is_last(const LmState &st, const L
     const double dH = 12.0 * n * dc * inv_rho;       // each j j^T moves by at most 2 sqrt2 * 2 (2 dc) / rho
     if (!(a >= 0.0 && lmin > 2.0 * dH))
         return false;
-    const double inv_lm2 = rcp_above(lmin - dH), kap = 1.0 + dH * inv_lm2;
+    const double lm2 = lmin - dH, inv_lm2 = rcp_above(lm2), kap = 1.0 + dH * inv_lm2;
     const double sn = (gn + Eg) * inv_lm2;            // no later step is longer
-    const double val = kap * (a + 2.0 * yn * Eg + Eg * Eg * rcp_above(lmin)) + sn * sn * (s1 * inv_rho);
-    if (!(val < 0.25 * prm.tol_cost && sn <= dc && 2.0 * sn <= rho))
+    // g'.H'^-1 g' from above; the most any step from p + d can gain is half of g'.(H' + B')^-1 g' plus the third-
+    // order term, B' being within dB of B in norm
+    const double gHg = kap * (a + 2.0 * yn * Eg + Eg * Eg * rcp_above(lmin));
+    const double Bn = fabs(B00) + 2.0 * fabs(B01) + fabs(B11);
+    const double dB = n * inv_rho * (move + 5.0 * (amax + move) * dc * inv_rho);
+    if (!(lm2 > 2.0 * (Bn + dB)))
+        return false;
+    const double gain = 0.5 * gHg * lm2 * rcp_above(lm2 - (Bn + dB)) + L3 * sn * sn * sn * (1.0 / 6.0);
+    if (!(gain < 0.5 * prm.tol_cost && sn <= dc && 2.0 * sn <= rho))
         return false;
     slack = dc;
     return true;
+}
+
+// Whether no candidate from the current parameters p can be accepted any more, by the second-order model (all
+// points regular; hg as for lm_model_step_is_last; gd = g.(H + lam D)^-1 g of the step just solved).  For any
+// step s that keeps the points regular  F(p + s) >= F(p) + g.s + s.(H + B)s / 2 - L3 |s|^3 / 6
+// >= F(p) - g.(H + B)^-1 g / 2 - L3 |s|^3 / 6,  and  g.H^-1 g <= (1 + lam max(D) / lmin(H)) gd.  A gain below
+// half of tol_cost is a rejection whatever the rounding of the two costs.
+__device__ __forceinline__ bool lm_regular_all_rejected(const LmState &st, const LmParams &prm, const double *hg,
+                                                        double gd)
+{
+    const double H00 = hg[0], H01 = hg[1], H02 = hg[2], H11 = hg[3], H12 = hg[4], H22 = hg[5];
+    const double g0 = hg[6], g1 = hg[7], g2 = hg[8];
+    const double n = H22, lo = hg[12], hi = hg[13], R = st.rad, F = st.prev;
+    const double det = H00 * (H11 * H22 - H12 * H12) - H01 * (H01 * H22 - H12 * H02) + H02 * (H01 * H12 - H11 * H02);
+    const double ht = 0.5 * (H00 + H11 + H22);
+    if (!(det > 0.0 && ht > 0.0 && n >= 3.0 && F >= 0.0))
+        return false;
+    const double lmin = det * rcp_nr(ht * ht) * (1.0 - 1e-9);
+    const double gn = sqrt_above(g0 * g0 + g1 * g1 + g2 * g2);
+    const double sn = gn * rcp_above(lmin);                  // no step from here is longer, whatever the damping
+    const double amax = fmax(hi - R, R - lo);
+    if (!(amax + 1.5 * sn <= prm.delta && 4.0 * sn <= lo))
+        return false;
+    const double inv_rho = rcp_above(lo - sn);
+    const double Bn = fabs(hg[16] - hg[14]) + 2.0 * fabs(hg[15]) + fabs(hg[14]);
+    if (!(lmin > 2.0 * Bn))
+        return false;
+    const double dmax = fmax(H00, fmax(H11, H22));
+    const double s1 = sqrt_above(2.0 * n * F) + 1.5 * n * sn;
+    const double L3 = (4.25 * n + 3.0 * s1 * inv_rho) * inv_rho;
+    const double gain = 0.5 * gd * (1.0 + st.lam * dmax * rcp_above(lmin)) * lmin * rcp_above(lmin - Bn) +
+                        L3 * sn * sn * sn * (1.0 / 6.0);
+    return gain < 0.5 * prm.tol_cost;
 }
 
 // after the sweep at (tx, ty, tr) has left its totals in area `into`.  AREA: doubles per totals area.  MODEL:
@@ -321,6 +363,10 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
                 break;
             }
             if constexpr (MODEL) {
+                if (st.regular && lm_regular_all_rejected(st, prm, hg, gd)) {
+                    st.it = prm.max_iter;
+                    break;
+                }
                 double slack;
                 if (st.regular && lm_model_step_is_last(st, prm, hg, slack)) {
                     st.cx = st.cx + st.step[0];

@@ -38,7 +38,7 @@ if "c3" in which:
 
 if "c4" in which:
     N, S = int(os.environ.get("C4N", 100_000_000)), int(os.environ.get("C4S", 2000))
-    pts = make_cylinder(N, S, seed=3, outlier_frac=0.1)
+    pts = make_cylinder(N, S, seed=3, outlier_frac=float(os.environ.get("C4OUT", 0.1)))
     xyz = t(pts); del pts
     zc = np.arange(1.0, 2.0 * S - 1.0 + 1e-9, 2.0); lo, hi = zc - 1.0, zc + 1.0
     dlo, dhi = t(lo), t(hi)
