@@ -1332,3 +1332,41 @@ def test_hull_sort_and_chain_paths_and_their_fall_backs():
             continue
         assert np.array_equal(h["hull_idx"][o:o + nh], N.hull(uniq)), s
     assert int(h["n_hull"][6]) <= 5                                         # the cascade: next to nothing is left of it
+
+
+def test_angular_bin_boundary_from_quick_angles_and_radii():
+    """The boundary kernel for up to 4096 bins decides bins and maxima from a polynomial angle and the reciprocal-
+    square-root radius and runs hypot / atan2 only over a short list of candidates: same selected indices as the
+    exact kernel (PCFIT_ANGLE_MAX_EXACT=1) and as the CPU, on points sitting on bin edges and axes, on the centre,
+    with the largest radius of a bin attained several times, on a coarse grid, with NaN, for 1 to 4096 bins."""
+    gen = np.random.default_rng(5)
+    sets = []
+    for n in (5, 300, 1023, 1024, 1025, 5000, 40_000):
+        th = gen.uniform(0, 2 * np.pi, n)
+        rr = 10.0 + gen.normal(0, 0.05, n)
+        sets.append(np.stack([3.0 + rr * np.cos(th), -2.0 + rr * np.sin(th)], 1))
+    k = np.arange(7200)
+    edge = np.stack([3.0 + 10.0 * np.cos(k * (2 * np.pi / 720)), -2.0 + 10.0 * np.sin(k * (2 * np.pi / 720))], 1)
+    edge[::3] = edge[1::3][: len(edge[::3])]                                 # radii attained twice
+    axes = np.array([[3.0, -2.0], [13.0, -2.0], [-7.0, -2.0], [3.0, 8.0], [3.0, -12.0], [13.0, -2.0], [3.0, -2.0],
+                     [13.0, 8.0], [-7.0, 8.0], [-7.0, -12.0], [13.0, -12.0]] * 30)
+    grid = np.round(sets[5] * 4.0) / 4.0
+    holes = sets[4].copy()
+    holes[::7] = np.nan
+    holes[1::50, 0] = np.nan
+    sets += [edge, axes, grid, holes]
+    x, y, off = csr(sets)
+    fit = np.tile([3.0, -2.0, 10.0], (len(sets), 1))
+    fit[3] = [3.0 + 1e-3, -2.0 - 2e-3, 10.0]
+    for bins in (1, 7, 90, 720, 3600, 4096):
+        quick = F.angle_max_batch(x, y, off, fit, bins=bins)
+        os.environ["PCFIT_ANGLE_MAX_EXACT"] = "1"
+        try:
+            exact = F.angle_max_batch(x, y, off, fit, bins=bins)
+        finally:
+            del os.environ["PCFIT_ANGLE_MAX_EXACT"]
+        assert np.array_equal(quick, exact), bins
+        # (the CPU restatement takes no NaN; with points on the very edges of bins its libm's atan2 and the
+        # device's, one ulp apart, may name different bins)
+        for s in (0, 2, 6, 8, 9):
+            assert np.array_equal(N.angle_max(sets[s], fit[s][0], fit[s][1], bins), quick[s]), (bins, s)
