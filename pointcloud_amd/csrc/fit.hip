@@ -191,8 +191,10 @@ struct SliceView {
     // how many points full_groups() hands to each thread
     __device__ __forceinline__ int32_t full_points_per_thread() const { return n / (GROUP * FIT_BLOCK) * GROUP; }
 
+    // halt (streamed slices only): when the pointed-to flag is set in any lane of the wave after a group, the
+    // wave leaves the remaining groups alone
     template <class FG>
-    __device__ __forceinline__ void full_groups(FG &&fg) const
+    __device__ __forceinline__ void full_groups(FG &&fg, const bool *halt = nullptr) const
     {
         constexpr int U = GROUP;
         if constexpr (STREAM) {
@@ -216,6 +218,8 @@ struct SliceView {
             fetch(ax, ay, 0);
             fetch(bx, by, 1);
             for (int32_t t = 0; t < trips; t += 3) {
+                if (halt && __builtin_amdgcn_ballot_w64(*halt) != 0ull)
+                    break;
                 fetch(cx, cy, t + 2);
                 fg(ax, ay, t * (U * FIT_BLOCK) + (int32_t)threadIdx.x);
                 fetch(ax, ay, t + 3);
@@ -510,6 +514,9 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                 acc[k] = 0.0;
             low = inf;
             high = -inf;
+            // (a streamed slice: a wave that has met a point the short form is not made for stops there - the
+            // sweep will be run again in the general form anyway - instead of reading the slice to its end)
+            bool stop = false;
             P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t) {
 #pragma unroll
                 for (int u = 0; u < U; u++) {
@@ -537,7 +544,9 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     acc[14] = acc[14] + q;
                     low = min_no_nan(low, ri);
                 }
-            });
+                if constexpr (View::STREAM)
+                    stop = !(max_no_nan(high - pr, pr - low) <= delta) || low < 1e-6;
+            }, View::STREAM ? &stop : nullptr);
             // a point was not regular: a residual beyond the threshold, or a NaN (which a distance of
             // zero gives here as well) that the sum of squares has kept
             // (the largest |residual| sits at the largest or at the smallest distance; without points -inf)
