@@ -583,3 +583,23 @@ def year_boundary_rows(results, year, thickness):
             rows.append(dict(year=year, z_center=result['z_center'], cx=cx, cy=cy, R=R, thickness=thickness,
                              theta=np.nan, delta_r=np.nan, boundary_point_index=0))
     return rows
+
+
+def year_summary_rows(results, year, thickness):
+    """Rows of year_{Y}_summary.csv, one per slice, as gui.py:1444-1455 builds them."""
+    return [dict(year=year, z_center=r['z_center'], cx=r['cx'], cy=r['cy'], R=r['R'], thickness=thickness,
+                 ovality_pct=r.get('ovality_pct', np.nan), n_boundary_points=len(r.get('boundary_points', [])))
+            for r in results]
+
+
+def year_match(df, current_z, current_thickness):
+    """The comparison view's choice of rows from one year file (gui.py:1926-1945): None for a file without the
+    required columns or without the slice, else (year as text, the slice's rows sorted by theta)."""
+    required_cols = ['year', 'z_center', 'thickness', 'theta', 'delta_r']
+    if not all(col in df.columns for col in required_cols):
+        return None
+    matching = df[(np.isclose(df['z_center'], current_z, atol=1e-3)) &
+                  (np.isclose(df['thickness'], current_thickness, atol=1e-3))]
+    if matching.empty:
+        return None
+    return str(matching['year'].iloc[0]), matching.sort_values('theta')

@@ -72,7 +72,7 @@ template <int PT_R, int PT_L, int FIT_BLOCK>
 struct SliceView {
     static constexpr bool STREAM = PT_R == 0 && PT_L == 0;
     // (with 64 VGPRs of points per thread a group of 4 no longer fits the register file beside them)
-    static constexpr int GROUP = (STREAM || (PT_R % 4 == 0 && PT_L % 4 == 0)) ? 4 : 1;
+    static constexpr int GROUP = (STREAM || (PT_R % 4 == 0 && PT_L % 4 == 0)) ? 4 : (PT_R % 2 == 0 && PT_L % 2 == 0) ? 2 : 1;
     static constexpr int STRIDE = FIT_BLOCK;
     static constexpr int LDS_DOUBLES = 2 * PT_L * FIT_BLOCK;       // what the points take of lds_dyn
     const double *xs, *ys;
@@ -148,6 +148,9 @@ struct SliceView {
             // every load is unconditional (a point past the end reads the slice's last one and is then
             // replaced by zero), so that all of them can be in flight together
             const int32_t last = n - 1;
+            // how many of this thread's points lie inside the slice (point k of the thread does when k < mine:
+            // one register for all the tests below instead of an index per point)
+            const int32_t mine = (int32_t)threadIdx.x < n ? (last - (int32_t)threadIdx.x) / FIT_BLOCK + 1 : 0;
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
                 const int32_t i = threadIdx.x + k * FIT_BLOCK;
@@ -165,18 +168,16 @@ struct SliceView {
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
-                const int32_t i = threadIdx.x + k * FIT_BLOCK;
-                take(rx[k], ry[k], i < n);
-                rx[k] = i < n ? rx[k] : 0.0;
-                ry[k] = i < n ? ry[k] : 0.0;
+                take(rx[k], ry[k], k < mine);
+                rx[k] = k < mine ? rx[k] : 0.0;
+                ry[k] = k < mine ? ry[k] : 0.0;
             }
 #pragma unroll
             for (int k = 0; k < PT_L; k++) {
-                const int32_t i = threadIdx.x + (PT_R + k) * FIT_BLOCK;
                 const int32_t j = (int32_t)threadIdx.x + k * FIT_BLOCK;
                 lds_dyn[2 * j] = tx[k];
                 lds_dyn[2 * j + 1] = ty[k];
-                take(tx[k], ty[k], i < n);
+                take(tx[k], ty[k], PT_R + k < mine);
             }
         } else {
 #pragma unroll
@@ -440,6 +441,8 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     // and the others take it from LDS: their SIMDs are free for the workgroup next door meanwhile.
     double *share = red.share();
     if (lead) {
+        // (a chain of dependent operations that the other waves wait for: it goes first on its SIMD)
+        __builtin_amdgcn_s_setprio(2);
         const int st = kasa_from_moments(m, mx, my, n, out);
         if (threadIdx.x == 0) {
             share[0] = out[0];
@@ -447,6 +450,7 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
             share[2] = out[2];
             share[3] = (double)st;
         }
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     out[0] = share[0];
@@ -593,6 +597,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     while (!done) {
         sweep(tx, ty, tr, red.totals(into));
         if (threadIdx.x < WAVE) {
+            __builtin_amdgcn_s_setprio(2);           // (the step is what the other waves wait for)
             // (a short-form sweep that met a point it is not made for says so in place of the smallest distance)
             const bool again = !general && red.totals(into)[12] == -inf;
             if (!again)
@@ -620,6 +625,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     ishare[6] = st.cur >= 0 ? 1 : 0;
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         if (ishare[7]) {
@@ -965,8 +971,12 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
 
 // Kasa -> LM -> residual statistics with the slice read from HBM once.
 // Dynamic LDS: the view's points, then (H+1) doubles of edges, then H int32 counters.
-template <int PT_R, int PT_L, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
+// WITH_LM false: the kernel for max_iter = 0 (the Kasa circle is the result).  Without the LM loop's code the
+// working set beside the points is some 60 registers, so the shape with 22 points of a thread in registers and
+// 10 in LDS (40 KB) runs three workgroups to a CU: the pass is bound by the latency of a workgroup's chain of
+// load, reduction, circle and residual sweep, not by arithmetic, and a third workgroup hides more of it.
+template <int PT_R, int PT_L, int FIT_BLOCK, bool WITH_LM>
+__global__ __launch_bounds__(FIT_BLOCK, (!WITH_LM && PT_L == 10 ? 3 : 2)) void fit_residual_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
     double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
     int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
@@ -982,24 +992,43 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
-    P.load(x, y, off, n);
-    ph.mark(0);
     constexpr int base = SliceView<PT_R, PT_L, FIT_BLOCK>::LDS_DOUBLES;
+    // The edges a thread will put into LDS are asked for before the slice, so that they arrive under the slice's
+    // loads instead of costing a trip to memory of their own after them (up to 512 bins here; more: below).
+    constexpr int EDGE_AHEAD = 2;
+    double edge_ahead[EDGE_AHEAD];
+    const double e0 = H > 0 ? edges[0] : 0.0, eH = H > 0 ? edges[H] : 0.0;      // (uniform addresses: scalar loads)
+#pragma unroll
+    for (int k = 0; k < EDGE_AHEAD; k++) {
+        const int b = threadIdx.x + k * FIT_BLOCK;
+        edge_ahead[k] = H > 0 ? edges[b <= H ? b : H] : 0.0;
+    }
     if (threadIdx.x == 0)
         edges_off = 0;
     if (H > 0)
         for (int b = threadIdx.x; b < hist_copies(H) * hist_stride(H); b += FIT_BLOCK)
             reinterpret_cast<int32_t *>(lds_dyn + base + H + 1)[b] = 0;
-    for (int b = threadIdx.x; b <= H && H > 0; b += FIT_BLOCK)
-        lds_dyn[base + b] = edges[b];
-    __syncthreads();
+    P.load(x, y, off, n);
+    if constexpr (PT_L == 0)
+        __syncthreads();                // (edges_off is cleared before anyone may set it; with points in LDS load() ends on a barrier)
+    ph.mark(0);
     if (H > 0) {
         // uniform to 2^-22 of a bin: what lets residual_slice take a bin number from a product
-        const double e0 = edges[0], eH = edges[H];
         const double width = (eH - e0) / (double)H, per_bin = (double)H / (eH - e0);
         bool ok = true;
-        for (int b = threadIdx.x; b <= H; b += FIT_BLOCK)
-            ok &= fabs(edges[b] - fma((double)b, width, e0)) * per_bin <= 2.384185791015625e-07;
+#pragma unroll
+        for (int k = 0; k < EDGE_AHEAD; k++) {
+            const int b = threadIdx.x + k * FIT_BLOCK;
+            if (b <= H) {
+                lds_dyn[base + b] = edge_ahead[k];
+                ok &= fabs(edge_ahead[k] - fma((double)b, width, e0)) * per_bin <= 2.384185791015625e-07;
+            }
+        }
+        for (int b = threadIdx.x + EDGE_AHEAD * FIT_BLOCK; b <= H; b += FIT_BLOCK) {
+            const double e = edges[b];
+            lds_dyn[base + b] = e;
+            ok &= fabs(e - fma((double)b, width, e0)) * per_bin <= 2.384185791015625e-07;
+        }
         if (!ok)
             edges_off = 1;
     }
@@ -1014,8 +1043,10 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_residual_kernel(
     int32_t it[4] = {0, 0, 0, 0};
     double reach[2] = {0.0, 0.0};
     bool have_reach = false;
-    if (st != PCFIT_ST_SPARSE)
-        have_reach = lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph, reach);
+    if constexpr (WITH_LM) {
+        if (st != PCFIT_ST_SPARSE)
+            have_reach = lm_slice<FIT_BLOCK / WAVE>(P, prm, red, c, it, ph, reach);
+    }
     __syncthreads();
     residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin, wthr, edges_off == 0,
                    have_reach, reach);
@@ -1041,8 +1072,11 @@ struct FitShape {
     int block, pr, pl;
 };
 
-static FitShape pick_shape(int64_t max_len)
+static FitShape pick_shape(int64_t max_len, bool three_per_cu = false)
 {
+    // (three workgroups to a CU: 22 + 10 points per thread; only the kernel without the LM loop has the registers)
+    static const int allow3 = [] { const char *e = getenv("PCFIT_FIT_THREE_PER_CU"); return e ? atoi(e) : 1; }();
+    if (three_per_cu && allow3 && max_len > 4096 && max_len <= 8192) return {256, 22, 10};
     if (max_len <= 0) return {256, 0, 0};
     if (max_len <= 64) return {64, 1, 0};
     if (max_len <= 256) return {256, 1, 0};
@@ -1060,8 +1094,8 @@ struct ShapeTag {
     static constexpr size_t lds_points = (size_t)PL * B * 16;
 };
 
-// calls f(ShapeTag<block, pr, pl>)
-template <class F>
+// calls f(ShapeTag<block, pr, pl>); WITH_3: the caller has a kernel for the three-to-a-CU shape
+template <bool WITH_3 = false, class F>
 static void dispatch_shape(FitShape sh, F &&f)
 {
     const int key = (sh.block * 100 + sh.pr) * 100 + sh.pl;
@@ -1072,6 +1106,12 @@ static void dispatch_shape(FitShape sh, F &&f)
     case (256 * 100 + 8) * 100: f(ShapeTag<256, 8, 0>{}); break;
     case (256 * 100 + 16) * 100: f(ShapeTag<256, 16, 0>{}); break;
     case (256 * 100 + 16) * 100 + 16: f(ShapeTag<256, 16, 16>{}); break;
+    case (256 * 100 + 22) * 100 + 10:
+        if constexpr (WITH_3) {
+            f(ShapeTag<256, 22, 10>{});
+            break;
+        }
+        [[fallthrough]];
     default: f(ShapeTag<256, 0, 0>{}); break;
     }
 }
@@ -1141,13 +1181,23 @@ int launch_fit_residual(const double *x, const double *y, const int64_t *offsets
     if (S == 0) return PCFIT_OK;
     const size_t lds_hist = H > 0 ? (size_t)(H + 1) * 8 + (size_t)hist_copies(H) * hist_stride(H) * 4 : 0;
     int rc = PCFIT_OK;
-    dispatch_shape(pick_shape(max_len), [&](auto t) {
-        using T = decltype(t);
-        auto kern = fit_residual_kernel<T::pr, T::pl, T::block>;
-        if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
-        kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
-            x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
-    });
+    if (prm.max_iter == 0) {
+        dispatch_shape<true>(pick_shape(max_len, true), [&](auto t) {
+            using T = decltype(t);
+            auto kern = fit_residual_kernel<T::pr, T::pl, T::block, false>;
+            if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
+            kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
+                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
+        });
+    } else {
+        dispatch_shape(pick_shape(max_len), [&](auto t) {
+            using T = decltype(t);
+            auto kern = fit_residual_kernel<T::pr, T::pl, T::block, true>;
+            if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
+            kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
+                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
+        });
+    }
     PCFIT_TRY(rc);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;

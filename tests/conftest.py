@@ -48,3 +48,15 @@ def same_cycle(a, b):
         return False
     k = a.index(b[0])
     return a[k:] + a[:k] == b
+
+
+def year_fixture():
+    """The window state the GUI's year export ran on (results with boundary points) and what it wrote."""
+    g = load_golden("year_export")
+    off = g["boundary_offsets"]
+    results = []
+    for s, (z, cx, cy, r, ov) in enumerate(g["scalars"]):
+        b = g["boundary_xy"][off[s]:off[s + 1]]
+        results.append(dict(z_center=float(z), cx=float(cx), cy=float(cy), R=float(r), ovality_pct=float(ov),
+                            boundary_points=b.tolist()))
+    return g, results

@@ -387,6 +387,136 @@ def g_long_slices():
     save("long_slices", **out)
 
 
+# 13. the GUI's year export and the comparison's slice matcher (gui.py:1357-1466, 1921-1945) --------------
+def gui_year_functions():
+    """``export_data_year`` and the file-matching statements of ``compare_years``, compiled out of gui.py
+    as they stand.  gui.py imports PyQt6 and VTK at its top, which the container lacks, and both are methods of
+    the main window; so the one method definition is compiled as a plain function of ``self`` and the
+    statements of the comparison loop up to the sorted table (lines 1921-1945) are compiled as the body of a
+    function.  The two dialogs that ``export_data_year`` opens are answered by stand-ins that return what a
+    user would enter (year text, directory); everything in between is the reference's own code."""
+    import ast
+    from datetime import datetime
+    import pandas as pd
+    path = os.path.join(REF, "gui.py")
+    tree = ast.parse(open(path, encoding="utf-8").read(), path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "CylinderAnalyzerGUI")
+    export_def = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "export_data_year")
+    compare_def = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "compare_years")
+    loop = next(n for n in ast.walk(compare_def) if isinstance(n, ast.For) and isinstance(n.iter, ast.Call)
+                and "comparison_files" in ast.unparse(n.iter))
+    attempt = loop.body[0]
+    assert isinstance(attempt, ast.Try)
+    kept = [s for s in attempt.body if not ast.unparse(s).startswith(("ax.", "valid_comparisons"))]
+    assert ast.unparse(kept[-1]).startswith("comparison_df_sorted = matching_slices.sort_values")
+    collect = ast.parse("found.append((file_path, comparison_year, comparison_df_sorted))").body
+    new_loop = ast.For(target=loop.target, iter=loop.iter, body=[ast.Try(body=kept + collect, handlers=attempt.handlers,
+                                                                          orelse=[], finalbody=[])], orelse=[])
+    matcher = ast.parse("def match_files(self, current_z, current_thickness):\n    found = []\n    return found").body[0]
+    matcher.body.insert(1, new_loop)
+    module = ast.fix_missing_locations(ast.Module(body=[export_def, matcher], type_ignores=[]))
+
+    class Answers:
+        year_text = ""
+        directory = ""
+
+    class QInputDialog:
+        @staticmethod
+        def getText(*a, **k):
+            return Answers.year_text, True
+
+    class QFileDialog:
+        class Option:
+            ShowDirsOnly = 1
+
+        @staticmethod
+        def getExistingDirectory(*a, **k):
+            return Answers.directory
+
+    ns = {"np": np, "pd": pd, "os": os, "datetime": datetime, "QInputDialog": QInputDialog, "QFileDialog": QFileDialog}
+    exec(compile(module, path, "exec"), ns)
+    return ns["export_data_year"], ns["match_files"], Answers
+
+
+def g_year_export():
+    export_data_year, match_files, answers = gui_year_functions()
+
+    class Spin:
+        def __init__(self, v):
+            self.v = v
+
+        def value(self):
+            return self.v
+
+    class Bar:
+        def __init__(self):
+            self.messages = []
+
+        def showMessage(self, m):
+            self.messages.append(m)
+
+    class Window:                       # what the two pieces of code read from the main window
+        def __init__(self, results, thickness):
+            self.current_results = results
+            self.slice_thickness = Spin(thickness)
+            self.bar = Bar()
+            self.comparison_files = []
+
+        def statusBar(self):
+            return self.bar
+
+    pts = make_cylinder(30_000, 8, seed=23, outlier_frac=0.02)
+    cfg = ran.Config(min_points_per_slice=300, save_plots=False) if "save_plots" in ran.Config.__dataclass_fields__ \
+        else ran.Config(min_points_per_slice=300)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        results = ran.CylinderAnalyzer(cfg).analyze_with_progress(pts)
+    results = [dict(r) for r in results]
+    results.append(dict(results[0], z_center=99.0, boundary_points=[]))     # a slice without boundary points
+    d = tempfile.mkdtemp(prefix="pcfit_year_")
+    out = {}
+    win = Window(results, 2.0)
+    answers.year_text, answers.directory = " 2023 ", d
+    export_data_year(win)
+    assert win.bar.messages and win.bar.messages[-1].startswith("Year 2023 data exported"), win.bar.messages
+    bpath = os.path.join(d, "year_2023_boundary_data.csv")
+    spath = os.path.join(d, "year_2023_summary.csv")
+    out["boundary_csv"] = np.frombuffer(open(bpath, "rb").read(), np.uint8)
+    out["summary_csv"] = np.frombuffer(open(spath, "rb").read(), np.uint8)
+    # a second year with another thickness, for the matcher's thickness key
+    win2 = Window(results[:3], 1.5)
+    answers.year_text = "2021"
+    export_data_year(win2)
+    b2 = os.path.join(d, "year_2021_boundary_data.csv")
+    out["boundary_csv_2021"] = np.frombuffer(open(b2, "rb").read(), np.uint8)
+    # the inputs: what the window held
+    out["n_results"] = np.array(len(results))
+    out["scalars"] = np.array([[r["z_center"], r["cx"], r["cy"], r["R"], r.get("ovality_pct", np.nan)] for r in results])
+    cnt = np.array([len(r["boundary_points"]) for r in results], np.int64)
+    out["boundary_offsets"] = np.concatenate([[0], np.cumsum(cnt)])
+    out["boundary_xy"] = np.concatenate([np.asarray(r["boundary_points"], float).reshape(-1, 2) for r in results])
+    # the matcher: queries (z, thickness) over the files [2023, summary (invalid format), 2021]
+    files = [bpath, spath, b2]
+    queries = [(results[3]["z_center"] + 4e-4, 2.0), (results[1]["z_center"], 1.5), (results[3]["z_center"] + 0.5, 2.0),
+               (results[2]["z_center"] - 9e-4, 2.0009), (99.0, 2.0)]
+    out["queries"] = np.array(queries)
+    for q, (z, t) in enumerate(queries):
+        win.comparison_files = files
+        win.bar.messages.clear()
+        found = match_files(win, z, t)
+        out[f"match{q}_files"] = np.array([files.index(f) for f, _, _ in found], np.int64)
+        for f, year, table in found:
+            k = files.index(f)
+            assert isinstance(year, str)
+            out[f"match{q}_{k}_year"] = np.array(year)
+            out[f"match{q}_{k}_index"] = table.index.to_numpy().astype(np.int64)
+            out[f"match{q}_{k}_theta"] = table["theta"].to_numpy()
+            out[f"match{q}_{k}_delta_r"] = table["delta_r"].to_numpy()
+        out[f"match{q}_messages"] = np.array(win.bar.messages)
+    save("year_export", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[2:]
     if only:
@@ -402,3 +532,4 @@ if __name__ == "__main__":
     g_boundary()
     g_analyzer()
     g_long_slices()
+    g_year_export()

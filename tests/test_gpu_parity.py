@@ -1049,10 +1049,48 @@ def test_scan_level_call_matches_bin_then_hybrid():
     assert np.array_equal(c["cand_x"], a["cand_x"]) and np.array_equal(c["fit"], a["fit"], equal_nan=True)
 
 
+def test_year_export_equals_the_files_the_gui_wrote(tmp_path):
+    """export_year_data / match_year_slices on the recorded window state of tests/golden/year_export.npz:
+    the bytes the reference's own export_data_year (gui.py:1357-1466) wrote and the rows its comparison loop
+    (gui.py:1921-1945) picked.  theta and delta_r come from the GPU residual kernel; its correctly rounded hypot
+    and the device atan2 can differ from numpy's by an ulp, which '%.6f' shows on a line in many thousands at most."""
+    import io
+    import pandas as pd
+    from conftest import year_fixture
+    from pointcloud_amd.utils.year_export import export_year_data, match_year_slices
+    g, results = year_fixture()
+    bpath, spath = export_year_data(results, " 2023 ", 2.0, str(tmp_path))
+    b2, _ = export_year_data(results[:3], "2021", 1.5, str(tmp_path))
+    assert os.path.basename(bpath) == "year_2023_boundary_data.csv" and os.path.basename(spath) == "year_2023_summary.csv"
+    assert open(spath, "rb").read() == g["summary_csv"].tobytes()
+    for path, key in ((bpath, "boundary_csv"), (b2, "boundary_csv_2021")):
+        got = open(path, "rb").read().splitlines()
+        want = g[key].tobytes().splitlines()
+        assert len(got) == len(want) and got[0] == want[0]
+        assert sum(a != b for a, b in zip(got, want)) <= len(want) // 1000, key
+        a = pd.read_csv(path)
+        b = pd.read_csv(io.BytesIO(g[key].tobytes()))
+        assert a.drop(columns=["theta", "delta_r"]).equals(b.drop(columns=["theta", "delta_r"]))
+        assert np.allclose(a[["theta", "delta_r"]].to_numpy(), b[["theta", "delta_r"]].to_numpy(), rtol=0, atol=1.01e-6,
+                           equal_nan=True)
+    files = [bpath, spath, b2]
+    for q, (z, t) in enumerate(g["queries"]):
+        hits = []
+        for k, f in enumerate(files):
+            m = match_year_slices(f, z, t)
+            if m is None:
+                continue
+            hits.append(k)
+            assert m[0] == str(g[f"match{q}_{k}_year"])
+            assert np.array_equal(m[1].index.to_numpy(), g[f"match{q}_{k}_index"])
+            assert np.allclose(m[1]["theta"].to_numpy(), g[f"match{q}_{k}_theta"], rtol=0, atol=1.01e-6, equal_nan=True)
+        assert hits == g[f"match{q}_files"].tolist(), q
+
+
 def test_year_export_files_and_matcher(tmp_path):
-    """year_{Y}_boundary_data.csv / year_{Y}_summary.csv against the row-by-row restatement of
-    gui.py:1388-1459 written with the same pandas call; the reference's GUI code cannot be
-    imported (PyQt6 absent), so this format is pinned by the restatement only."""
+    """year_{Y}_boundary_data.csv / year_{Y}_summary.csv of a fresh analysis against the row-by-row restatement of
+    gui.py:1388-1459 written with the same pandas call (the restatement itself is pinned to the reference's bytes by
+    tests/test_oracle_np.py)."""
     import pandas as pd
     from pointcloud_amd import Config, CylinderAnalyzer
     from pointcloud_amd.synth import make_cylinder

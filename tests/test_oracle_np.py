@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import load_golden, same_cycle, ulp_diff
+from conftest import load_golden, same_cycle, ulp_diff, year_fixture
 from oracle import ref_np as R
 
 REL = 1e-12      # same numpy/LAPACK calls as the reference: equal up to BLAS kernel choice
@@ -242,3 +242,29 @@ def test_filtered_residual_profile_rules():
     td, dr, kept = R.filtered_residual_profile(xy, 3.0, -2.0, 10.0, inlier_mask=mask[:-1])
     assert kept.sum() == 380 and np.abs(dr).max() < 1.0       # the outliers are gone
     assert np.allclose(np.sort(np.degrees(th[kept])), td)
+
+
+def test_year_export_files_and_matcher_of_the_gui(tmp_path):
+    """gui.py:1357-1466 (export_data_year) and gui.py:1921-1945 (the comparison's slice matcher), run from the
+    reference's own source on recorded results: the restatement writes the same bytes and picks the same rows."""
+    import io
+    import pandas as pd
+    g, results = year_fixture()
+    for key, res, year, thick in (("boundary_csv", results, "2023", 2.0), ("boundary_csv_2021", results[:3], "2021", 1.5)):
+        text = pd.DataFrame(R.year_boundary_rows(res, year, thick)).to_csv(index=False, float_format="%.6f")
+        assert text.encode() == g[key].tobytes(), key
+    text = pd.DataFrame(R.year_summary_rows(results, "2023", 2.0)).to_csv(index=False, float_format="%.6f")
+    assert text.encode() == g["summary_csv"].tobytes()
+    files = [g["boundary_csv"], g["summary_csv"], g["boundary_csv_2021"]]
+    for q, (z, t) in enumerate(g["queries"]):
+        hits = []
+        for k, raw in enumerate(files):
+            m = R.year_match(pd.read_csv(io.BytesIO(raw.tobytes())), z, t)
+            if m is None:
+                continue
+            hits.append(k)
+            assert m[0] == str(g[f"match{q}_{k}_year"])
+            assert np.array_equal(m[1].index.to_numpy(), g[f"match{q}_{k}_index"])
+            assert np.array_equal(m[1]["theta"].to_numpy(), g[f"match{q}_{k}_theta"], equal_nan=True)
+            assert np.array_equal(m[1]["delta_r"].to_numpy(), g[f"match{q}_{k}_delta_r"], equal_nan=True)
+        assert hits == g[f"match{q}_files"].tolist(), q
