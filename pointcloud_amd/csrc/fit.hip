@@ -441,8 +441,6 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     // and the others take it from LDS: their SIMDs are free for the workgroup next door meanwhile.
     double *share = red.share();
     if (lead) {
-        // (a chain of dependent operations that the other waves wait for: it goes first on its SIMD)
-        __builtin_amdgcn_s_setprio(2);
         const int st = kasa_from_moments(m, mx, my, n, out);
         if (threadIdx.x == 0) {
             share[0] = out[0];
@@ -450,7 +448,6 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
             share[2] = out[2];
             share[3] = (double)st;
         }
-        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     out[0] = share[0];
@@ -597,7 +594,6 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     while (!done) {
         sweep(tx, ty, tr, red.totals(into));
         if (threadIdx.x < WAVE) {
-            __builtin_amdgcn_s_setprio(2);           // (the step is what the other waves wait for)
             // (a short-form sweep that met a point it is not made for says so in place of the smallest distance)
             const bool again = !general && red.totals(into)[12] == -inf;
             if (!again)
@@ -625,8 +621,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     ishare[6] = st.cur >= 0 ? 1 : 0;
                 }
             }
-            __builtin_amdgcn_s_setprio(0);
-        }
+            }
         __syncthreads();
         if (ishare[7]) {
             general = true;                         // the same sweep once more, in the general form
@@ -653,7 +648,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
 }
 
 template <int PT_R, int PT_L, int FIT_BLOCK>
-__global__ __launch_bounds__(FIT_BLOCK, 2) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
+__global__ __launch_bounds__(FIT_BLOCK, (PT_L == 10 ? 3 : 2)) void kasa_kernel(const double *__restrict__ x, const double *__restrict__ y,
                                                         const int64_t *__restrict__ offsets, double *__restrict__ out,
                                                         int32_t *__restrict__ status)
 {
@@ -1131,7 +1126,7 @@ int launch_kasa(const double *x, const double *y, const int64_t *offsets, int64_
 {
     if (S == 0) return PCFIT_OK;
     int rc = PCFIT_OK;
-    dispatch_shape(pick_shape(max_len), [&](auto t) {
+    dispatch_shape<true>(pick_shape(max_len, true), [&](auto t) {
         using T = decltype(t);
         auto kern = kasa_kernel<T::pr, T::pl, T::block>;
         if ((rc = allow_lds(kern, T::lds_points)) != PCFIT_OK) return;

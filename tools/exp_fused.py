@@ -17,6 +17,8 @@ amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
 p = lambda a: C.c_void_p(a.data_ptr())
 if os.environ.get("PHASES"):
     F.SO_PATH = F.SO_PATH.replace("libpcfit_hip.so", "libpcfit_hip_phase.so")
+if os.environ.get("SO"):                       # another build of the library, for A/B runs on one box
+    F.SO_PATH = F.SO_PATH.replace("libpcfit_hip.so", os.environ["SO"])
 L = F.lib(); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 tag = f"S={S} n={n}"
 
