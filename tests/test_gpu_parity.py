@@ -583,7 +583,7 @@ def test_fused_fit_residual_launch_equals_the_separate_kernels():
     assert st[-1] == 1 and np.all(np.isnan(of_.cpu().numpy()[-1]))
 
 
-def _fused_dev(x, y, off, H, lo, hi, want_resid=True):
+def _fused_dev(x, y, off, H, lo, hi, want_resid=True, max_iter=100):
     """pcfit_fit_residuals_batch_dev (or pcfit_fit_batch_dev) on device copies of the inputs."""
     import ctypes as C
     import torch
@@ -599,7 +599,7 @@ def _fused_dev(x, y, off, H, lo, hi, want_resid=True):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     mx = int(np.diff(off).max())
     if want_resid:
-        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, mx, 1.0, 100, 1e-2, 1e-10, 1e-12,
+        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, mx, 1.0, max_iter, 1e-2, 1e-10, 1e-12,
                                                       p(ok_), p(of_), p(oi), p(os_), H, p(dedge), p(oh), p(orm),
                                                       p(oam), st))
     else:
@@ -631,6 +631,8 @@ def test_fused_residual_pass_where_the_quick_radius_cannot_decide():
     dev = torch.device("cuda", 0)
     gen = np.random.default_rng(2024)
 
+    max_iter = [100]
+
     def fused(pts, edges):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
         p = lambda a: C.c_void_p(a.data_ptr())
@@ -640,11 +642,13 @@ def test_fused_residual_pass_where_the_quick_radius_cannot_decide():
         it, st_ = torch.empty(1, 4, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev)
         hist = torch.full((1, H), -5, dtype=torch.int64, device=dev)
         rmm, amm = torch.empty(1, 2, dtype=torch.float64, device=dev), torch.empty(1, 2, dtype=torch.int64, device=dev)
-        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), 1, n, 1.0, 100, 1e-2, 1e-10, 1e-12, p(kas),
-                                                      p(fit), p(it), p(st_), H, p(dedge), p(hist), p(rmm), p(amm),
+        F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), 1, n, 1.0, max_iter[0], 1e-2, 1e-10, 1e-12,
+                                                      p(kas), p(fit), p(it), p(st_), H, p(dedge), p(hist), p(rmm), p(amm),
                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
         torch.cuda.synchronize()
         c = lambda a: a.cpu().numpy()
+        if max_iter[0] == 0:                    # the kernel without the LM loop: the Kasa circle is the result
+            assert np.array_equal(c(fit), c(kas)) and not c(it).any()
         return c(fit)[0], c(hist)[0], c(rmm)[0], c(amm)[0]
 
     def check(pts, edges, tag):
@@ -654,7 +658,10 @@ def test_fused_residual_pass_where_the_quick_radius_cannot_decide():
         assert np.array_equal(rmm, r) and np.array_equal(amm, a), tag
         return fit
 
-    for n in (8192, 7000, 4100, 2048, 1024, 1023, 300):
+    # (max_iter = 0 is a kernel of its own - no LM loop, three workgroups to a CU from 4097 points on - with its
+    # thresholds for the extremes taken from the first points of the slice)
+    for mi, n in [(100, n) for n in (8192, 7000, 4100, 2048, 1024, 1023, 300)] + [(0, n) for n in (8192, 7000, 4100, 1023)]:
+        max_iter[0] = mi
         pts = R.make_slab(n, 500 + n, outlier=0.0)[:, :2]
         H = 256
         fit = check(pts, np.linspace(-0.5, 0.5, H + 1), (n, "plain"))
@@ -735,6 +742,20 @@ def test_fit_on_ragged_slices_of_up_to_8192_points():
     again = _fused_dev(x, y, off, H, lo, hi)
     for key in a:
         assert np.array_equal(a[key], again[key], equal_nan=True), key          # bitwise reproducible
+    # max_iter = 0: the kernel without the LM loop (22 points of a thread in registers, 10 in LDS, three workgroups
+    # to a CU); the Kasa circle is the fit and the residual statistics are exact about it
+    z = _fused_dev(x, y, off, H, lo, hi, max_iter=0)
+    assert np.array_equal(z["status"], st) and not z["iters"].any()
+    assert np.array_equal(z["fit"], z["kasa"], equal_nan=True) and rel(z["kasa"][ok], k[ok]) < 1e-11
+    assert np.all(np.isnan(z["fit"][~ok]))
+    res0 = F.residuals_batch(x, y, off, z["fit"], bins=H, lo=lo, hi=hi, want_theta=False, want_dr=False)
+    assert np.array_equal(z["hist"][ok], res0["hist"][ok])
+    assert np.array_equal(z["amm"][ok, 0], res0["argmax"][ok]) and np.array_equal(z["amm"][ok, 1], res0["argmin"][ok])
+    assert np.array_equal(z["rmm"][ok, 0], res0["rmax"][ok]) and np.array_equal(z["rmm"][ok, 1], res0["rmin"][ok])
+    for s_ in (0, 1, 2, 4, 12):
+        sl = slice(off[s_], off[s_ + 1])
+        h, r_, a_ = _oracle_resid(np.stack([x[sl], y[sl]], 1), z["fit"][s_], np.linspace(lo, hi, H + 1))
+        assert np.array_equal(z["hist"][s_], h) and np.array_equal(z["rmm"][s_], r_) and np.array_equal(z["amm"][s_], a_)
 
 
 def test_long_slices_on_the_segment_parallel_kernels():
