@@ -116,8 +116,9 @@ def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600, threads=1):
 
 def extra_configs(L, dev, stream):
     """Timings of the other configurations, outside the timed region (events on the kernels' stream):
-    seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice; binning of
-    100 M points in random z order into 2000 windows (both steps of the two-level form, nothing read back)."""
+    seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice; a 100 M-point
+    scan in random z order: binning into 2000 windows (both steps of the two-level form, nothing read back), then
+    Kasa + LM fits, the 720-bin boundary and the 256-bin residual histograms of the 2000 windows."""
     out = {}
 
     def timed(fn, reps):
@@ -158,9 +159,22 @@ def extra_configs(L, dev, stream):
     del x, y, off, tab, tof, model, score, best, st, mask, ws
     torch.cuda.empty_cache()
 
+    # a 100 M-point scan of a noisy cylinder (sigma 0.05 about R = 10, 10 % outliers anywhere inside 1.4 R), rows in
+    # random z order, 2000 windows of ~50 000 points: binning, then fits, angular-bin boundary and histograms
     n, S = 100_000_000, 2000
-    xyz = torch.rand(n, 3, generator=g, device=dev, dtype=torch.float64)
+    xyz = torch.empty(n, 3, device=dev, dtype=torch.float64)
+    xyz[:, 2] = torch.rand(n, generator=g, device=dev, dtype=torch.float64)
     xyz[:, 2] *= 2.0 * S
+    xyz[:, 0] = torch.rand(n, generator=g, device=dev, dtype=torch.float64)          # angle / 2 pi
+    xyz[:, 1] = 10.0 + 0.05 * torch.randn(n, generator=g, device=dev, dtype=torch.float64)
+    bad = torch.rand(n, generator=g, device=dev, dtype=torch.float64) < 0.1
+    xyz[:, 1] = torch.where(bad, torch.rand(n, generator=g, device=dev, dtype=torch.float64) * 14.0, xyz[:, 1])
+    del bad
+    ang = xyz[:, 0] * (2 * np.pi)
+    rr = xyz[:, 1].clone()
+    xyz[:, 0] = 3.0 + rr * torch.cos(ang)
+    xyz[:, 1] = -2.0 + rr * torch.sin(ang)
+    del ang, rr
     lo = 2.0 * torch.arange(S, device=dev, dtype=torch.float64)
     hi = lo + 2.0
     geom = np.array([0.0, 2.0, 2.0 * (S - 1)])
@@ -185,6 +199,36 @@ def extra_configs(L, dev, stream):
         "points_per_s": n / (ms * 1e-3), "status": int(status.item()), "members": int(off[-1].item()),
         "gbs_at_64_bytes_per_point_single_pass": 64.0 * n / (ms * 1e-3) / 1e9,
         "hbm_frac_at_64_bytes_per_point": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    # the passes over the binned scan: each reads x, y of every window member (16 B) once per sweep
+    del xyz, ws
+    torch.cuda.empty_cache()
+    tot = int(off[-1].item())
+    longest = int((off[1:] - off[:-1]).max().item())
+    kasa, fit = (torch.empty(S, 3, dtype=torch.float64, device=dev) for _ in range(2))
+    iters = torch.empty(S, 4, dtype=torch.int32, device=dev)
+    st = torch.empty(S, dtype=torch.int32, device=dev)
+    ms_fit = timed(lambda: F.check(L.pcfit_fit_batch_dev(ptr(xo), ptr(yo), ptr(off), S, longest, 1.0, 100, 1e-2, 1e-10,
+                                                         1e-12, ptr(kasa), ptr(fit), ptr(iters), ptr(st), stream)), 3)
+    sweeps = float((iters[:, 2] + iters[:, 3]).double().mean().item())
+    sel = torch.empty(S, 720, dtype=torch.int64, device=dev)
+    ms_sel = timed(lambda: F.check(L.pcfit_angle_max_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), 720, ptr(sel),
+                                                               stream)), 3)
+    H = 256
+    edges = torch.linspace(-0.5, 0.5, H + 1, dtype=torch.float64, device=dev)
+    hist = torch.empty(S, H, dtype=torch.int64, device=dev)
+    rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
+    amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
+    ms_hist = timed(lambda: F.check(L.pcfit_residuals_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), None, None, None,
+                                                                H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream)), 3)
+    gbs = lambda ms_, passes: 16.0 * tot * passes / (ms_ * 1e-3) / 1e9
+    out["boundary_and_histograms_100M_points_2000_windows"] = {
+        "ms_binning": ms, "ms_kasa_lm_fit": ms_fit, "mean_lm_sweeps": sweeps,
+        "ms_angular_bin_boundary_720": ms_sel, "ms_residual_histogram_256": ms_hist,
+        "ms_total": ms + ms_fit + ms_sel + ms_hist, "points_per_s": n / ((ms + ms_fit + ms_sel + ms_hist) * 1e-3),
+        "longest_window": longest, "all_fits_ok": bool((st == 0).all().item()),
+        "hbm_gbs_boundary_two_passes": gbs(ms_sel, 2), "hbm_frac_boundary": gbs(ms_sel, 2) / PEAK_HBM_GBS,
+        "hbm_gbs_histogram": gbs(ms_hist, 1), "hbm_frac_histogram": gbs(ms_hist, 1) / PEAK_HBM_GBS,
+        "hbm_gbs_fit_per_sweep": gbs(ms_fit, sweeps + 1), "hbm_frac_fit_per_sweep": gbs(ms_fit, sweeps + 1) / PEAK_HBM_GBS}
     return out
 
 
@@ -359,7 +403,7 @@ def main():
             ("fit_kernel (Kasa + LM)", lambda: F.check(L.pcfit_fit_batch_dev(
                 ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit_side), ptr(iters_side),
                 ptr(status), stream))),
-            ("fit_residual_kernel with max_iter = 0 (Kasa + residual pass, one read of the slice)",
+            ("fit_residual_kernel without the LM loop (max_iter = 0: Kasa + residual pass, one read of the slice)",
              lambda: F.check(L.pcfit_fit_residuals_batch_dev(
                  ptr(x), ptr(y), ptr(off), S, n, 1.0, 0, 1e-2, 1e-10, 1e-12, ptr(kasa), ptr(fit_side), ptr(iters_side),
                  ptr(status), H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream))),
@@ -403,8 +447,8 @@ def main():
                                                                          f", {a.backend} all-gather through host memory (launch rehearsal)")
                                                                         if world > 1 else "")},
             # The metric asks for the fraction of the HBM roofline; the pass itself is bound by FP64 vector
-            # issue (see roofline_valu), so this fraction cannot approach 1: three LM sweeps, the Kasa
-            # moments and a correctly rounded hypot per point are ~220 vector instructions per 16 bytes.
+            # issue (see roofline_valu), so this fraction cannot approach 1: two LM sweeps, the Kasa power
+            # sums and the residual decisions are ~140 vector instructions per point of 16 bytes.
             "roofline": {
                 "kernel": "fit_residual_kernel<16,16,256> (Kasa + LM + residuals, one read of the slice)",
                 "bound": "hbm",
@@ -428,7 +472,8 @@ def main():
         if side:
             kr = side[2]
             out["roofline_kasa_residual_pass"] = {
-                "kernel": "fit_residual_kernel<16,16,256> with max_iter = 0", "bound": "hbm", "achieved": kr["hbm_gbs"],
+                "kernel": "fit_residual_kernel<22,10,256,false> (max_iter = 0: no LM loop, three workgroups to a CU)",
+                "bound": "hbm", "achieved": kr["hbm_gbs"],
                 "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": kr["hbm_frac"], "avg_launch_ms": kr["ms"],
                 "algorithmic_bytes": alg_bytes}
         if not a.no_extra:

@@ -970,13 +970,16 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
 // working set beside the points is some 60 registers, so the shape with 22 points of a thread in registers and
 // 10 in LDS (40 KB) runs three workgroups to a CU: the pass is bound by the latency of a workgroup's chain of
 // load, reduction, circle and residual sweep, not by arithmetic, and a third workgroup hides more of it.
-template <int PT_R, int PT_L, int FIT_BLOCK, bool WITH_LM>
-__global__ __launch_bounds__(FIT_BLOCK, (!WITH_LM && PT_L == 10 ? 3 : 2)) void fit_residual_kernel(
+// GIVEN (with WITH_LM false): no fit at all - the circle of slice s is given[3 s ..] and only the residual
+// statistics are taken (the streamed shape: one pass over the slice, the loads of two trips in flight).
+template <int PT_R, int PT_L, int FIT_BLOCK, bool WITH_LM, bool GIVEN = false>
+__global__ __launch_bounds__(FIT_BLOCK, (GIVEN ? 4 : !WITH_LM && PT_L == 10 ? 3 : 2)) void fit_residual_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets, LmParams prm,
     double *__restrict__ kasa_out, double *__restrict__ out, int32_t *__restrict__ iters,
     int32_t *__restrict__ status, int32_t H, const double *__restrict__ edges, int64_t *__restrict__ hist,
-    double *__restrict__ rmax_rmin, int64_t *__restrict__ argmax_argmin)
+    double *__restrict__ rmax_rmin, int64_t *__restrict__ argmax_argmin, const double *__restrict__ given)
 {
+    static_assert(!GIVEN || !WITH_LM, "a given circle is not refined");
     __shared__ double lds[RED_SIZE];
     __shared__ Extreme2 wmax[16], wmin[16];
     __shared__ double wthr[2 * 16];
@@ -1028,11 +1031,18 @@ __global__ __launch_bounds__(FIT_BLOCK, (!WITH_LM && PT_L == 10 ? 3 : 2)) void f
             edges_off = 1;
     }
     double c[3];
-    const int st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
-    if (threadIdx.x == 0 && kasa_out) {
-        kasa_out[3 * s] = c[0];
-        kasa_out[3 * s + 1] = c[1];
-        kasa_out[3 * s + 2] = c[2];
+    int st = PCFIT_ST_OK;
+    if constexpr (GIVEN) {
+        c[0] = given[3 * s];
+        c[1] = given[3 * s + 1];
+        c[2] = given[3 * s + 2];
+    } else {
+        st = kasa_slice<FIT_BLOCK / WAVE>(P, red, c);
+        if (threadIdx.x == 0 && kasa_out) {
+            kasa_out[3 * s] = c[0];
+            kasa_out[3 * s + 1] = c[1];
+            kasa_out[3 * s + 2] = c[2];
+        }
     }
     ph.mark(1);
     int32_t it[4] = {0, 0, 0, 0};
@@ -1046,7 +1056,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (!WITH_LM && PT_L == 10 ? 3 : 2)) void f
     residual_slice(P, c[0], c[1], c[2], H, base, s, hist, rmax_rmin, argmax_argmin, wmax, wmin, wthr, edges_off == 0,
                    have_reach, reach);
     ph.mark(5);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !GIVEN) {
         out[3 * s] = c[0];
         out[3 * s + 1] = c[1];
         out[3 * s + 2] = c[2];
@@ -1182,7 +1192,7 @@ int launch_fit_residual(const double *x, const double *y, const int64_t *offsets
             auto kern = fit_residual_kernel<T::pr, T::pl, T::block, false>;
             if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
             kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
-                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
+                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm, nullptr);
         });
     } else {
         dispatch_shape(pick_shape(max_len), [&](auto t) {
@@ -1190,10 +1200,25 @@ int launch_fit_residual(const double *x, const double *y, const int64_t *offsets
             auto kern = fit_residual_kernel<T::pr, T::pl, T::block, true>;
             if ((rc = allow_lds(kern, T::lds_points + lds_hist)) != PCFIT_OK) return;
             kern<<<dim3((unsigned)S), dim3(T::block), T::lds_points + lds_hist, st>>>(
-                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm);
+                x, y, offsets, prm, kasa_out, out, iters, status, H, edges, hist, rmm, amm, nullptr);
         });
     }
     PCFIT_TRY(rc);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+// residual statistics about given circles, no per-point output: the streamed shape of the fused kernel
+int launch_residual_stats(const double *x, const double *y, const int64_t *offsets, int64_t S, const double *cxcyr,
+                          int32_t H, const double *edges, int64_t *hist, double *rmm, int64_t *amm, hipStream_t st)
+{
+    if (S == 0) return PCFIT_OK;
+    const size_t lds_hist = H > 0 ? (size_t)(H + 1) * 8 + (size_t)hist_copies(H) * hist_stride(H) * 4 : 0;
+    auto kern = fit_residual_kernel<0, 0, 256, false, true>;
+    PCFIT_TRY(allow_lds(kern, lds_hist));
+    const LmParams prm{0.0, 0.0, 0.0, 0.0, 0};
+    kern<<<dim3((unsigned)S), dim3(256), lds_hist, st>>>(x, y, offsets, prm, nullptr, nullptr, nullptr, nullptr, H, edges,
+                                                         hist, rmm, amm, cxcyr);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }

@@ -12,6 +12,10 @@ namespace pcfit {
 
 constexpr int RES_BLOCK = 256;
 
+// fit.hip: the residual pass of the fused fit kernel about given circles (statistics only)
+int launch_residual_stats(const double *x, const double *y, const int64_t *offsets, int64_t S, const double *cxcyr,
+                          int32_t H, const double *edges, int64_t *hist, double *rmm, int64_t *amm, hipStream_t st);
+
 struct Extreme {
     double r;
     int64_t i;
@@ -334,6 +338,13 @@ PCFIT_API int pcfit_residuals_batch_dev(const double *x, const double *y, const 
         return PCFIT_OK;
     PCFIT_REQUIRE(x && y && offsets && cxcyr && rmax_rmin && argmax_argmin, "residuals: null pointer");
     PCFIT_REQUIRE(n_bins == 0 || (edges && hist), "residuals: histogram asked for without edges/hist");
+    // Statistics only (histogram, extremes): the fused fit kernel's residual pass about the given circles - bins and
+    // extremes from the reciprocal-square-root radius, the correctly rounded hypot only where that cannot decide,
+    // the loads of two trips in flight.  (read at every call so that a test can compare the two kernels)
+    const char *env = getenv("PCFIT_RESIDUALS_EXACT");
+    if (!theta && !dr && !radius && n_bins <= 4096 && !(env && atoi(env)))
+        return launch_residual_stats(x, y, offsets, n_slices, cxcyr, n_bins, edges, hist, rmax_rmin, argmax_argmin,
+                                     as_stream(stream));
     const size_t lds = n_bins > 0 ? (size_t)(n_bins + 1) * 8 + (size_t)n_bins * 4 : 0;
     // more than 64 KB of dynamic LDS has to be granted explicitly (per device; idempotent)
     if (lds > 48 * 1024)

@@ -758,6 +758,74 @@ def test_fit_on_ragged_slices_of_up_to_8192_points():
         assert np.array_equal(z["hist"][s_], h) and np.array_equal(z["rmm"][s_], r_) and np.array_equal(z["amm"][s_], a_)
 
 
+def _resid_stats_dev(x, y, off, fit, bins, lo, hi):
+    """pcfit_residuals_batch_dev without per-point outputs, on device copies (one workgroup per slice whatever its length)."""
+    import ctypes as C
+    import torch
+    S = len(off) - 1
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda a: C.c_void_p(a.data_ptr()) if a is not None else None
+    dx, dy, doff, dfit = t(x), t(y), t(off), t(fit)
+    dedge = t(np.linspace(lo, hi, bins + 1)) if bins else None
+    hist = torch.full((S, max(bins, 1)), -7, dtype=torch.int64, device=dev)
+    rmm, amm = torch.empty(S, 2, dtype=torch.float64, device=dev), torch.empty(S, 2, dtype=torch.int64, device=dev)
+    F.check(F.lib().pcfit_residuals_batch_dev(p(dx), p(dy), p(doff), S, p(dfit), None, None, None, bins, p(dedge),
+                                              p(hist) if bins else None, p(rmm), p(amm),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    c = lambda a: a.cpu().numpy()
+    return dict(hist=c(hist)[:, :bins], rmax=c(rmm)[:, 0], rmin=c(rmm)[:, 1], argmax=c(amm)[:, 0], argmin=c(amm)[:, 1])
+
+
+def test_statistics_only_residual_pass_equals_the_per_point_kernel():
+    """Without per-point outputs the residual statistics come from the fused kernel's residual pass about the
+    given circles (quick radius, exact code only where it cannot decide, thresholds for the extremes from the first
+    points of a slice); with PCFIT_RESIDUALS_EXACT=1 from the kernel that takes the correctly rounded hypot of
+    every point.  Same counts, extremes and first indices, on ragged batches of every size class (streamed slices
+    beyond 8192 points included), clean and with outliers, for several bin counts and ranges, circles off the data,
+    a slice of identical points and points that are not numbers; three slices per batch replayed on the C restatement."""
+    gen = np.random.default_rng(5)
+    lens = np.array([8192, 0, 1, 2, 3, 255, 256, 257, 1023, 1024, 1025, 4100, 8193, 20001, 7000, 64, 100])
+    S = len(lens)
+    off = np.zeros(S + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    for outlier in (0.0, 0.2):
+        x, y, _ = R.make_slices(1, int(lens.sum()), seed=31, outlier_frac=outlier, jitter=0.05)
+        x, y = x.copy(), y.copy()
+        x[off[9]:off[10]] = 1.25                                   # a slice of identical points
+        y[off[9]:off[10]] = -0.5
+        x[off[11] + 17] = np.nan                                   # not a number: counted nowhere, never an extreme
+        y[off[14] + 4000] = np.inf
+        k, _ = F.kasa_batch(x, y, off)
+        fit = np.where(np.isfinite(k), k, 1.0)
+        fit[5] = [100.0, 100.0, 5.0]                              # a circle far from its points
+        fit[6, :2] = [x[off[6] + 3], y[off[6] + 3]]              # a centre on a point
+        for bins, lo, hi in ((256, -0.5, 0.5), (0, 0.0, 1.0), (1, -0.1, 0.1), (64, -20.0, 20.0), (4096, -0.3, 0.3),
+                             (200, 0.01, 0.02)):
+            os.environ["PCFIT_RESIDUALS_EXACT"] = "1"
+            try:
+                want = _resid_stats_dev(x, y, off, fit, bins, lo, hi)
+            finally:
+                del os.environ["PCFIT_RESIDUALS_EXACT"]
+            got = _resid_stats_dev(x, y, off, fit, bins, lo, hi)
+            host = F.residuals_batch(x, y, off, fit, bins=bins, lo=lo, hi=hi, want_theta=False, want_dr=False)
+            tag = (outlier, bins, lo, hi)
+            for key in ("rmax", "rmin", "argmax", "argmin") + (("hist",) if bins else ()):
+                assert np.array_equal(host[key], want[key], equal_nan=True), (tag, key, "host entry point")
+            if bins:
+                assert np.array_equal(got["hist"], want["hist"]), tag
+            for key in ("rmax", "rmin", "argmax", "argmin"):
+                assert np.array_equal(got[key], want[key], equal_nan=True), (tag, key)
+            if bins:
+                for s_ in (0, 13, int(gen.integers(0, S))):
+                    sl = slice(off[s_], off[s_ + 1])
+                    h, r_, a_ = _oracle_resid(np.stack([x[sl], y[sl]], 1), fit[s_], np.linspace(lo, hi, bins + 1))
+                    assert np.array_equal(got["hist"][s_], h), (tag, s_)
+                    if lens[s_]:
+                        assert got["argmax"][s_] == a_[0] and got["argmin"][s_] == a_[1] and got["rmax"][s_] == r_[0]
+
+
 def test_long_slices_on_the_segment_parallel_kernels():
     """Batches with a slice of more than 8192 points are cut into segments, one workgroup each, and combined
     per slice in a fixed order: a mix of lengths around the segment size, empty and tiny slices, outliers."""
