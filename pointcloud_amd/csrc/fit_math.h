@@ -369,8 +369,13 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
                 }
                 double slack;
                 if (st.regular && lm_model_step_is_last(st, prm, hg, slack)) {
-                    st.cx = st.cx + st.step[0];
-                    st.cy = st.cy + st.step[1];
+                    // (how far the centre really goes: far from the origin the rounding of the two sums can exceed
+                    // the step itself, and the bounds below must hold for the centre that is returned)
+                    const double ncx = st.cx + st.step[0], ncy = st.cy + st.step[1];
+                    const double gx = ncx - st.cx, gy = ncy - st.cy;
+                    slack = fmax(slack, sqrt_above(gx * gx + gy * gy));
+                    st.cx = ncx;
+                    st.cy = ncy;
                     st.rad = st.rad + st.step[2];
                     st.acc_steps++;
                     st.min_ri += slack * (1.0 + 1e-9);

@@ -7,6 +7,7 @@ import sys
 import time
 
 import numpy as np
+import torch  # noqa: F401  (first, so that the process runs on ONE HIP runtime: the one torch ships)
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import native as N           # noqa: E402
@@ -26,6 +27,26 @@ def note(seed, s, what, detail=""):
 def rel(a, b):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300))) if a.size else 0.0
+
+
+def fused_dev(x, y, off, H, lo, hi, max_iter):
+    """pcfit_fit_residuals_batch_dev on device copies of the batch."""
+    import ctypes as C
+    S = len(off) - 1
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    dx, dy, doff, dedge = t(x if len(x) else np.zeros(1)), t(y if len(y) else np.zeros(1)), t(off), t(np.linspace(lo, hi, H + 1))
+    ok_, of_ = torch.empty(S, 3, dtype=torch.float64, device=dev), torch.empty(S, 3, dtype=torch.float64, device=dev)
+    oi, os_ = torch.empty(S, 4, dtype=torch.int32, device=dev), torch.empty(S, dtype=torch.int32, device=dev)
+    oh = torch.zeros(S, H, dtype=torch.int64, device=dev)
+    orm, oam = torch.empty(S, 2, dtype=torch.float64, device=dev), torch.empty(S, 2, dtype=torch.int64, device=dev)
+    F.check(F.lib().pcfit_fit_residuals_batch_dev(p(dx), p(dy), p(doff), S, int(np.diff(off).max()), 1.0, max_iter, 1e-2,
+                                                  1e-10, 1e-12, p(ok_), p(of_), p(oi), p(os_), H, p(dedge), p(oh), p(orm),
+                                                  p(oam), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    c = lambda a: a.cpu().numpy()
+    return dict(kasa=c(ok_), fit=c(of_), iters=c(oi), status=c(os_), hist=c(oh), rmm=c(orm), amm=c(oam))
 
 
 def make_slice(g, n):
@@ -68,6 +89,35 @@ def one_round(seed):
     init = np.where(np.isfinite(kasa), kasa, 1.0)
     lm, iters = F.lm_batch(x, y, off, init)
     res = F.residuals_batch(x, y, off, init, bins=64, lo=-0.5, hi=0.5)
+    # statistics only: another kernel (the fused kernel's residual pass about the given circles)
+    stat = F.residuals_batch(x, y, off, init, bins=64, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
+    for key in ("hist", "rmax", "rmin", "argmax", "argmin"):
+        if not np.array_equal(stat[key], res[key], equal_nan=True):
+            differ = np.flatnonzero([not np.array_equal(stat[key][s], res[key][s], equal_nan=True) for s in range(S)])
+            note(seed, int(differ[0]), "statistics-only residual pass", f"{key} [{kinds[differ[0]]} n={sizes[differ[0]]}]")
+    # the one-launch kernels (Kasa + LM + residual statistics; Kasa + residual statistics), device entry point
+    for max_iter in (100, 0):
+        fu = fused_dev(x, y, off, 64, -0.5, 0.5, max_iter)
+        okf = np.isfinite(fu["fit"]).all(axis=1)
+        # (exactly collinear or identical points: whether the determinant rounds to zero depends on the summation order)
+        plain = np.array([k not in ("line", "same") for k in kinds])
+        if not np.array_equal(fu["status"][plain], kst[plain]):
+            note(seed, -1, "fused status", f"max_iter {max_iter}")
+        about = np.where(okf[:, None], fu["fit"], 1.0)
+        chk = F.residuals_batch(x, y, off, about, bins=64, lo=-0.5, hi=0.5)          # the per-point kernel
+        for s in np.flatnonzero(okf):
+            tag = f"[{kinds[s]} n={sizes[s]} max_iter={max_iter}]"
+            if not (np.array_equal(fu["hist"][s], chk["hist"][s]) and fu["amm"][s, 0] == chk["argmax"][s]
+                    and fu["amm"][s, 1] == chk["argmin"][s] and fu["rmm"][s, 0] == chk["rmax"][s]
+                    and fu["rmm"][s, 1] == chk["rmin"][s]):
+                note(seed, int(s), "fused residual statistics", tag)
+            if max_iter == 0 and not np.array_equal(fu["fit"][s], fu["kasa"][s]):
+                note(seed, int(s), "fused fit without LM is not its Kasa circle", tag)
+            if kinds[s] in ("ring", "dups", "tiny", "grid") and sizes[s] >= 3:
+                want = lm[s] if max_iter else kasa[s]
+                err = float(np.max(np.abs(fu["fit"][s] - want)) / np.abs(want).max())     # against the circle's size
+                if not err <= 1e-9:
+                    note(seed, int(s), "fused fit", f"{tag} {err:.2e}")
     sel = F.angle_max_batch(x, y, off, init, bins=90)
     uh = F.unique_hull_batch(x, y, off)
     rs = F.ransac_batch(x, y, off, max_trials=150)
@@ -95,7 +145,8 @@ def one_round(seed):
             # 1e-15 perturbation of the input moves the CPU result by 1e-6 - conditioning, not arithmetic)
             if kinds[s] == "arc" and abs(want[2]) > 100.0:
                 tol = 1e-4
-            scale = np.abs(want).max() if kinds[s] == "far" else None
+            # (errors against the circle's size where a centre coordinate may be arbitrarily close to zero)
+            scale = np.abs(want).max() if kinds[s] in ("far", "tiny") else None
             err = float(np.max(np.abs(lm[s] - want)) / scale) if scale else rel(lm[s], want)
             if not (err <= tol):
                 note(seed, s, "lm value", f"{tag} {err:.2e}")

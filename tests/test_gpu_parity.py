@@ -692,6 +692,15 @@ def test_fused_residual_pass_where_the_quick_radius_cannot_decide():
             r2 = np.hypot(twice[:, 0] - fit2[0], twice[:, 1] - fit2[1])
             if np.argmax(r2) in (i_hi, j_hi):
                 assert amm[0] == min(i_hi, j_hi)
+    # A million units from the origin the last, modelled, LM step is of the size of the centre's own rounding: the
+    # centre that is returned may lie twice as far from the last sweep's as the step says, and the bounds on the
+    # extreme distances that the residual pass takes over from that sweep have to allow for it (they once did
+    # not, and the true smallest radius went unexamined).
+    max_iter[0] = 100
+    for k in range(60):
+        n = int(gen.choice([1420, 2049, 1024, 4096, 8192, 5000]))
+        far = R.make_slab(n, 9000 + k, outlier=0.0)[:, :2] + np.array([1.0e6, -2.0e6])
+        check(far, np.linspace(-0.5, 0.5, 65), (n, k, "far from the origin"))
     # a symmetric cloud with four points at the origin: the smallest radius is three orders below the rest
     q = R.make_slab(1024, 77)[:, :2] - np.array([3.0, -2.0])
     sym = np.concatenate([q, q * [-1, 1], q * [1, -1], q * [-1, -1]])
