@@ -79,25 +79,29 @@ struct SliceView {
     int32_t n;
     double rx[PT_R > 0 ? PT_R : 1], ry[PT_R > 0 ? PT_R : 1];
     // This thread's share of the power sums of u = x - x0, v = y - y0 about the slice's first point (x0, y0),
-    // taken while the slice is loaded (not STREAM): su sv suu svv suv suuu svvv suvv svuu.  The algebraic fit
-    // needs moments about the mean; these give them without a pass of their own and without waiting for the
-    // mean (kasa_slice), and the first point is as near the data as any shift known before the loads return.
-    double m9[9];
+    // taken while the slice is loaded (not STREAM): su sv suu sz suv suz svz with z = u^2 + v^2 (the fit needs
+    // the third moments only as sum u z and sum v z).  The algebraic fit needs moments about the mean; these
+    // give them without a pass of their own and without waiting for the mean (kasa_slice), and the first point
+    // is as near the data as any shift known before the loads return.
+    static constexpr int NSUM = 7;
+    double m9[NSUM];
     double x0, y0;
+
+    __device__ __forceinline__ static void power_sums(double (&q)[NSUM], double u, double v)
+    {
+        const double uu = u * u, z = fma(v, v, uu);
+        q[0] += u;
+        q[1] += v;
+        q[2] += uu;
+        q[3] += z;
+        q[4] = fma(u, v, q[4]);
+        q[5] = fma(u, z, q[5]);
+        q[6] = fma(v, z, q[6]);
+    }
 
     __device__ __forceinline__ void take(double vx, double vy, bool valid)
     {
-        const double u = valid ? vx - x0 : 0.0, v = valid ? vy - y0 : 0.0;
-        const double uu = u * u, vv = v * v;
-        m9[0] += u;
-        m9[1] += v;
-        m9[2] += uu;
-        m9[3] += vv;
-        m9[4] = fma(u, v, m9[4]);
-        m9[5] = fma(uu, u, m9[5]);
-        m9[6] = fma(vv, v, m9[6]);
-        m9[7] = fma(u, vv, m9[7]);
-        m9[8] = fma(v, uu, m9[8]);
+        power_sums(m9, valid ? vx - x0 : 0.0, valid ? vy - y0 : 0.0);
     }
 
     __device__ __forceinline__ void load(const double *x, const double *y, int64_t off, int64_t count)
@@ -113,7 +117,7 @@ struct SliceView {
         // its arithmetic: raise the priority of these waves so that their loads get issued at once.
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll
-        for (int k = 0; k < 9; k++)
+        for (int k = 0; k < NSUM; k++)
             m9[k] = 0.0;
         x0 = n > 0 ? xs[0] : 0.0;           // (uniform addresses: scalar loads)
         y0 = n > 0 ? ys[0] : 0.0;
@@ -392,49 +396,41 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
     const bool lead = threadIdx.x < WAVE;
-    double m[7];   // suu svv suv suuu svvv suvv svuu, about the mean
+    double m[5];   // sum of u^2, v^2, u v, u z, v z about the mean (z = u^2 + v^2)
     double mx = 0.0, my = 0.0;
     // the power sums about the slice's first point: they came with the loads, or (a slice that is streamed) a
     // pass over the points takes them; one reduction, then the moments about the mean by the binomial
     // identities (a, b = the mean, seen from the first point)
-    double q[9];
+    constexpr int NS = View::NSUM;
+    double q[NS];
     if constexpr (View::STREAM) {
 #pragma unroll
-        for (int k = 0; k < 9; k++)
+        for (int k = 0; k < NS; k++)
             q[k] = 0.0;
         const double x0 = P.x0, y0 = P.y0;
         each_point(P, [&](double px, double py, int32_t, bool valid) {
-            const double u = valid ? px - x0 : 0.0, v = valid ? py - y0 : 0.0;
-            const double uu = u * u, vv = v * v;
-            q[0] += u;
-            q[1] += v;
-            q[2] += uu;
-            q[3] += vv;
-            q[4] = fma(u, v, q[4]);
-            q[5] = fma(uu, u, q[5]);
-            q[6] = fma(vv, v, q[6]);
-            q[7] = fma(u, vv, q[7]);
-            q[8] = fma(v, uu, q[8]);
+            View::power_sums(q, valid ? px - x0 : 0.0, valid ? py - y0 : 0.0);
         });
     } else {
 #pragma unroll
-        for (int k = 0; k < 9; k++)
+        for (int k = 0; k < NS; k++)
             q[k] = P.m9[k];
     }
     double *tot = red.totals(1);
-    block_reduce_to_lds<9, false, NW, false>(q, 0.0, red.scratch(), tot);
+    block_reduce_to_lds<NS, false, NW, false>(q, 0.0, red.scratch(), tot);
     if (lead) {
-        const double su = tot[0], sv = tot[1], suu = tot[2], svv = tot[3], suv = tot[4];
+        const double su = tot[0], sv = tot[1], suu = tot[2], sz = tot[3], suv = tot[4], suz = tot[5], svz = tot[6];
+        const double svv = sz - suu;
         const double a = su / n, b = sv / n;
         mx = P.x0 + a;
         my = P.y0 + b;
+        const double zc = sz - a * su - b * sv;             // sum of z about the mean
+        const double ab2 = a * a + b * b;
         m[0] = suu - a * su;
         m[1] = svv - b * sv;
         m[2] = suv - a * sv;
-        m[3] = tot[5] - 3.0 * a * suu + 2.0 * a * a * su;
-        m[4] = tot[6] - 3.0 * b * svv + 2.0 * b * b * sv;
-        m[5] = tot[7] - 2.0 * b * suv - a * svv + 2.0 * b * b * su;
-        m[6] = tot[8] - 2.0 * a * suv - b * suu + 2.0 * a * a * sv;
+        m[3] = suz - 2.0 * a * suu - 2.0 * b * suv + ab2 * su - a * zc;
+        m[4] = svz - 2.0 * b * svv - 2.0 * a * suv + ab2 * sv - b * zc;
     }
     // The circle from the moments (divisions, a square root: some 250 instructions) is the same in every thread.
     // The first wave - whose lanes have just written the totals, so it need not wait for anyone - works it out
@@ -497,8 +493,12 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     // the general one over the ragged group); when a point turns out not to be regular the sweep
     // is run again in the general form, and so are all later sweeps of this slice.  The totals are
     // left for the first wave to read (no barrier after they are written).
+    // The first sweep (H and g at the start) leaves the three model sums out - five instructions per point: they
+    // are read only when the candidate that follows is rejected, one slice in fifty, and that slice then goes on
+    // without the second-order model (its totals are marked as not regular).
     bool general = false;
-    auto sweep = [&](double px0, double py0, double pr, double *tot) {
+    auto sweep = [&](double px0, double py0, double pr, double *tot, auto with_model) {
+        constexpr bool MODEL_SUMS = decltype(with_model)::value;
         constexpr int U = View::GROUP;
         double acc[15];
         double low, high;
@@ -539,10 +539,12 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     acc[7] = fma(j1, r, acc[7]);
                     acc[8] = acc[8] - r;
                     acc[9] = fma(fabs(r), iv, acc[9]);
-                    const double q = r * iv, t0 = j0 * q;
-                    acc[12] = fma(t0, j0, acc[12]);
-                    acc[13] = fma(t0, j1, acc[13]);
-                    acc[14] = acc[14] + q;
+                    if constexpr (MODEL_SUMS) {
+                        const double q = r * iv, t0 = j0 * q;
+                        acc[12] = fma(t0, j0, acc[12]);
+                        acc[13] = fma(t0, j1, acc[13]);
+                        acc[14] = acc[14] + q;
+                    }
                     low = min_no_nan(low, ri);
                 }
                 if constexpr (View::STREAM)
@@ -591,13 +593,17 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
     double tx = st.tx, ty = st.ty, tr = st.tr;
     int into = 0;
     bool done = false;
+    bool first_sweep = true;
     while (!done) {
-        sweep(tx, ty, tr, red.totals(into));
+        if (first_sweep)
+            sweep(tx, ty, tr, red.totals(into), std::false_type{});
+        else
+            sweep(tx, ty, tr, red.totals(into), std::true_type{});
         if (threadIdx.x < WAVE) {
             // (a short-form sweep that met a point it is not made for says so in place of the smallest distance)
             const bool again = !general && red.totals(into)[12] == -inf;
             if (!again)
-                lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general);
+                lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general && !first_sweep);
             if (threadIdx.x == 0) {
                 ishare[7] = again ? 1 : 0;
                 share[0] = st.tx;
@@ -627,6 +633,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             general = true;                         // the same sweep once more, in the general form
             continue;                               // (the word is written again only after the sweep's barrier)
         }
+        first_sweep = false;
         tx = share[0];
         ty = share[1];
         tr = share[2];

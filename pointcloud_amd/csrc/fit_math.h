@@ -409,12 +409,12 @@ __device__ __forceinline__ void lm_finish(const LmState &st, double par[3], int3
     iters[3] = st.n_sweeps;    // sweeps that evaluated a candidate (cost, and H and g for the next step)
 }
 
-// Kasa: from the centred moments m = {suu svv suv suuu svvv suvv svuu} about (mx, my) of n points
+// Kasa: from the centred moments m = {suu svv suv suz svz} (z = u^2 + v^2) about (mx, my) of n points
 // to the circle; returns the status.
-__device__ __forceinline__ int kasa_from_moments(const double (&m)[7], double mx, double my, double n, double out[3])
+__device__ __forceinline__ int kasa_from_moments(const double (&m)[5], double mx, double my, double n, double out[3])
 {
     const double a = 2 * m[0], b = 2 * m[2], d = 2 * m[1];
-    const double r0 = m[3] + m[5], r1 = m[4] + m[6];
+    const double r0 = m[3], r1 = m[4];
     double uc, vc;
     const double det = solve2x2(a, b, r0, b, d, r1, uc, vc);
     int st = PCFIT_ST_OK;

@@ -167,8 +167,11 @@ __global__ __launch_bounds__(WAVE) void split_kasa_kernel(const int64_t *__restr
     double c[3];
     int st = PCFIT_ST_SPARSE;
     c[0] = c[1] = c[2] = __longlong_as_double(0x7ff8000000000000ll);
-    if (n >= 3)
-        st = kasa_from_moments(m, slices[s].mean[0], slices[s].mean[1], (double)n, c);
+    if (n >= 3) {
+        // (suu svv suv suuu svvv suvv svuu -> the third moments as sum u z and sum v z, z = u^2 + v^2)
+        const double m5[5] = {m[0], m[1], m[2], m[3] + m[5], m[4] + m[6]};
+        st = kasa_from_moments(m5, slices[s].mean[0], slices[s].mean[1], (double)n, c);
+    }
     if (threadIdx.x == 0) {
         cxcyr[3 * s] = c[0];
         cxcyr[3 * s + 1] = c[1];
