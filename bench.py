@@ -32,18 +32,22 @@ sys.path.insert(0, ROOT)
 from pointcloud_amd import _ffi as F            # noqa: E402
 from pointcloud_amd.synth import make_slices    # noqa: E402
 
-# How the flop figure of the kernel is counted: the arithmetic of the short form of each pass, per
-# point, an FMA as 2, everything else (add, mul, compare, min, the hardware reciprocal square root) as 1.
-#   Kasa: sums (2) + centred moments (2 sub, 2 mul, 2 add, 5 fma)                               = 18
-#   LM sweep: distance (2 sub, mul, fma), rsqrt + 2 Newton steps (10), ri, 1/ri (5), residual and
-#             its test (2), Jacobian (2 mul), 7 fma + 3 add into H, g, cost, curvature, min (1)   = 42
-#   residuals: exact sum of squares (13), rsqrt + Newton (10), correctly rounded root (9), dr,
-#              extremes (5), bin guess and repair (8)                                             = 45
-# The reference's literal loop evaluates residuals and Jacobian separately in each of its 100
-# iterations (~1e4 flop per point); the kernel reaches the same accept/reject sequence in 3 sweeps.
-FLOP_KASA = 18.0
-FLOP_SWEEP = 42.0
-FLOP_RESID = 45.0
+# How the flop figure of the kernel is counted: the arithmetic of the short form of each pass as the kernel
+# executes it, per point, a fused multiply-add as 2, everything else (add, mul, compare, min / max, floor, the
+# hardware reciprocal square root) as 1; integer work, moves, lane exchanges and the reductions are not counted.
+#   Kasa power sums: u, v (2 sub), u^2 (mul), z = u^2 + v^2 (fma), 4 adds, 3 fma                      = 15
+#   first LM sweep: distance (2 sub, mul, fma), rsqrt + third-order step (9), ri (fma), residual (sub),
+#             Jacobian (2 mul), 6 fma + 3 add into H, g, cost, curvature, largest / smallest distance (2) = 36
+#   candidate sweeps: the same + the three sums of the second-order model (2 mul, 2 fma, add)          = 43
+#   residual pass: distance (5), rsqrt + step (9), radius (mul), two tests for the extremes, bin
+#             (fma, floor, 2 sub, compare)                                                            = 23
+# The reference's literal loop evaluates residuals and Jacobian separately in each of its 100 iterations
+# (~1e4 flop per point); the kernel reaches the same accept/reject sequence in 2 sweeps (a third for a slice
+# in fifty).  The vector units issue ~132 instructions per point for these ~118 flop.
+FLOP_KASA = 15.0
+FLOP_SWEEP_FIRST = 36.0
+FLOP_SWEEP = 43.0
+FLOP_RESID = 23.0
 PEAK_FP64_VALU_TFLOPS = 78.6
 RING = 8                      # record buffers in flight between the fit kernel and the all-gather
 PEAK_HBM_GBS = 8000.0
@@ -418,7 +422,7 @@ def main():
     ms_step = dt / a.steps * 1e3
     k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_k]))
     sweeps = it[:, 2] + it[:, 3]
-    flop_launch = float(n * (FLOP_SWEEP * sweeps.sum() + (FLOP_KASA + FLOP_RESID) * S))
+    flop_launch = float(n * (FLOP_SWEEP_FIRST * it[:, 2].sum() + FLOP_SWEEP * it[:, 3].sum() + (FLOP_KASA + FLOP_RESID) * S))
     alg_bytes = float(S * n * 16)
 
     if rank == 0:
