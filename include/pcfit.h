@@ -154,7 +154,9 @@ int pcfit_fit_batch_dev(const double *x, const double *y, const int64_t *offsets
 /* The same, followed by the residual statistics of pcfit_residuals_batch_dev
  * about the fitted circle (histogram, Rmax / Rmin and their indices), all in
  * one launch: 16 bytes of HBM traffic per point for the whole fit + residual
- * pass.  At most 4096 bins. */
+ * pass.  At most 4096 bins.  max_iter = 0 (the Kasa circle is the result: the
+ * algebraic fit + residual statistics of analyzer.py:83-92 without the
+ * refinement) runs a kernel of its own without the LM loop's code. */
 int pcfit_fit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                   int64_t max_slice_len, double huber_delta, int32_t max_iter, double lm_lambda0,
                                   double tol_update, double tol_cost, double *kasa_out, double *out, int32_t *iters,
@@ -235,7 +237,10 @@ int pcfit_ransac_batch_static_dev(const double *x, const double *y, const int64_
 /* Per point theta = (atan2 + 2pi) mod 2pi, dr = hypot - R and radius = hypot
  * (each output nullable); per slice numpy.histogram(dr, bins=H, range=(edges[0], edges[H]))
  * with the H+1 edges given (device memory; H may be 0), Rmax/Rmin and the first
- * slice-local index attaining each. */
+ * slice-local index attaining each.  With all three per-point outputs NULL (and
+ * at most 4096 bins) the statistics come from one streamed pass that takes the
+ * correctly rounded hypot only of the points a quicker radius cannot decide:
+ * the same counts, extremes and indices. */
 int pcfit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                               const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
                               const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin,
