@@ -122,7 +122,8 @@ def extra_configs(L, dev, stream):
     """Timings of the other configurations, outside the timed region (events on the kernels' stream):
     seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice; a 100 M-point
     scan in random z order: binning into 2000 windows (both steps of the two-level form, nothing read back), then
-    Kasa + LM fits, the 720-bin boundary and the 256-bin residual histograms of the 2000 windows."""
+    Kasa + LM fits, the 720-bin boundary and the 256-bin residual histograms of the 2000 windows, and the analyzer's
+    hybrid analysis of the same scan kept resident."""
     out = {}
 
     def timed(fn, reps):
@@ -203,6 +204,29 @@ def extra_configs(L, dev, stream):
         "points_per_s": n / (ms * 1e-3), "status": int(status.item()), "members": int(off[-1].item()),
         "gbs_at_64_bytes_per_point_single_pass": 64.0 * n / (ms * 1e-3) / 1e9,
         "hbm_frac_at_64_bytes_per_point": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    # the analyzer's own path on that scan (CylinderAnalyzer.analyze_with_progress underneath: binning, interior
+    # filter, unique + hull, seeded RANSAC on the hull, Kasa + LM on the inliers, ovality), the scan resident in
+    # HBM (pcfit_scan_upload once, as the reference keeps a loaded scan in memory); per-window results and the
+    # hull candidates come back to the host in every call, which is timed by the host clock
+    from pointcloud_amd import DeviceScan
+    host = xyz.cpu().numpy()
+    zc = np.arange(1.0, 2.0 * S - 1.0 + 1e-9, 2.0)
+    t_up = time.perf_counter()
+    with DeviceScan(host) as scan:
+        t_up = time.perf_counter() - t_up
+        res = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
+        t_an = time.perf_counter()
+        for _ in range(3):
+            res = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
+        t_an = (time.perf_counter() - t_an) / 3
+    okw = res["status"] == 0
+    out["hybrid_analysis_100M_points_2000_windows_resident"] = {
+        "ms_per_analysis": t_an * 1e3, "points_per_s": n / t_an, "windows_fitted": int(okw.sum()),
+        # (the reference fits the hull's vertices: with outliers beyond the ring that is the outliers' outline)
+        "median_radius": float(np.median(res["fit"][okw, 2])) if okw.any() else None,
+        "candidates_returned": int(res["cand_offsets"][-1]),
+        "ms_upload_from_pageable_host_memory": t_up * 1e3, "upload_gb_per_s": host.nbytes / t_up / 1e9}
+    del host, res
     # the passes over the binned scan: each reads x, y of every window member (16 B) once per sweep
     del xyz, ws
     torch.cuda.empty_cache()
