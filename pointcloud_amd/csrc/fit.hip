@@ -502,13 +502,20 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
         constexpr int U = View::GROUP;
         double acc[15];
         double low, high;
-        auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check) {
+        // (the model sums: for the ragged end of a sweep in the short form that takes them; a sweep wholly in the
+        // general form is never marked regular and nobody reads them)
+        auto any_point = [&](const double (&px)[U], const double (&py)[U], int32_t i0, bool check, auto model_tag) {
 #pragma unroll
             for (int u = 0; u < U; u++)
-                lm_point_general(acc, low, high, px[u], py[u], px0, py0, pr, delta, root_delta,
-                                 !check || i0 + u * View::STRIDE < P.n);
+                lm_point_general<15, decltype(model_tag)::value>(acc, low, high, px[u], py[u], px0, py0, pr, delta,
+                                                                 root_delta, !check || i0 + u * View::STRIDE < P.n);
         };
-        auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, true); };
+        auto ragged = [&](const double (&px)[U], const double (&py)[U], int32_t i0) {
+            if (general)
+                any_point(px, py, i0, true, std::false_type{});
+            else
+                any_point(px, py, i0, true, std::integral_constant<bool, MODEL_SUMS>{});
+        };
         if (!general) {
 #pragma unroll
             for (int k = 0; k < 15; k++)
@@ -569,7 +576,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             acc[k] = 0.0;
         low = inf;
         high = -inf;
-        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false); });
+        P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false, std::false_type{}); });
         P.ragged_group(ragged);
         ph.mark(2);
         block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot);

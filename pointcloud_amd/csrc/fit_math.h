@@ -82,7 +82,7 @@ struct LmParams {
 //   with 15 accumulators also acc[12..14]: sums of q j0^2, q j0 j1 and q, q = residual / distance (the part of the
 //   cost's second derivative that H leaves out; taken as if no point were beyond the threshold)
 //   low / high = smallest / largest distance
-template <int NA>
+template <int NA, bool MODEL = (NA >= 15)>
 __device__ __forceinline__ void lm_point_general(double (&acc)[NA], double &low, double &high, double px, double py,
                                                  double px0, double py0, double pr, double delta, double root_delta,
                                                  bool valid)
@@ -99,11 +99,12 @@ __device__ __forceinline__ void lm_point_general(double (&acc)[NA], double &low,
     const double a = fabs(res);
     const bool big = a > delta;
     const double sw = root_delta * rsqrt_nr(a + 1e-16);      // sqrt(delta / (a + 1e-16))
-    double j0 = -dx * iv, j1 = -dy * iv;
-    j0 = big ? j0 * sw : j0;
-    j1 = big ? j1 * sw : j1;
-    double j2 = big ? -sw : -1.0;
-    double rw = big ? res * sw : res;
+    // (the Huber weight as a factor that is exactly one for a small residual: three products in place of four
+    // selects of doubles, same bits either way)
+    const double f = big ? sw : 1.0;
+    double j0 = (-dx * iv) * f, j1 = (-dy * iv) * f;
+    double j2 = -f;
+    double rw = res * f;
     double psi = big ? delta : a;
     j0 = valid ? j0 : 0.0;
     j1 = valid ? j1 : 0.0;
@@ -123,7 +124,7 @@ __device__ __forceinline__ void lm_point_general(double (&acc)[NA], double &low,
     acc[7] = fma(j1, rw, acc[7]);
     acc[8] = fma(j2, rw, acc[8]);
     acc[9] = fma(psi, iv, acc[9]);
-    if constexpr (NA >= 15) {
+    if constexpr (NA >= 15 && MODEL) {
         const double q = valid ? res * iv : 0.0;
         const double t0 = (valid ? -dx * iv : 0.0) * q;
         acc[12] = fma(t0, -dx * iv, acc[12]);
