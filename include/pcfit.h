@@ -240,7 +240,8 @@ int pcfit_ransac_batch_static_dev(const double *x, const double *y, const int64_
  * slice-local index attaining each.  With all three per-point outputs NULL (and
  * at most 4096 bins) the statistics come from one streamed pass that takes the
  * correctly rounded hypot only of the points a quicker radius cannot decide:
- * the same counts, extremes and indices. */
+ * the same counts, extremes and indices (slices of up to 2^31 - 1 points, as
+ * for the fit kernels). */
 int pcfit_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                               const double *cxcyr, double *theta, double *dr, double *radius, int32_t n_bins,
                               const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin,
