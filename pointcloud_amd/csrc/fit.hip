@@ -374,18 +374,33 @@ __device__ __forceinline__ void each_point(const View &P, F &&f)
 // first wave hands the others what it has worked out alone (the Kasa circle; the LM loop's next candidate, in
 // the end its result).
 constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE = RED_TOT + 2 * RED_AREA,
-              RED_SIZE = RED_SHARE + 16;
+              RED_STATE = RED_SHARE + 16, RED_SIZE = RED_STATE + LM_STATE_DOUBLES;
 
 // Where the next reduction of a workgroup puts its partial sums.  Alternating
 // between two scratch areas (and never writing totals that may still be read)
 // lets a reduction do without a barrier on entry.
+// Which wave does the work that falls to one wave - the circle from the Kasa moments, every step of the LM loop
+// between two sweeps (several hundred dependent instructions each): a different wave each time (turn), starting
+// from a wave that differs from workgroup to workgroup.  The waves of a workgroup sit on different SIMDs; with one
+// fixed wave for all of it, that wave's SIMD - shared with the same wave of the CU's other workgroup - carried a
+// third more instructions than the other three and set the pace.
 struct RedCtx {
     double *lds;
     int count;
+    int first_owner, turn, waves;
     __device__ __forceinline__ double *scratch() { return lds + (count++ & 1) * RED_SCR; }
     __device__ __forceinline__ double *totals(int which) { return lds + RED_TOT + RED_AREA * which; }
     __device__ __forceinline__ double *share() { return lds + RED_SHARE; }
+    __device__ __forceinline__ double *state() { return lds + RED_STATE; }
+    __device__ __forceinline__ int owner() const { return (first_owner + turn) % waves; }
+    __device__ __forceinline__ void next_owner() { turn++; }
 };
+
+__device__ __forceinline__ RedCtx make_red(double *lds)
+{
+    const int waves = (int)(blockDim.x >> 6);
+    return RedCtx{lds, 0, (int)(blockIdx.x % (unsigned)waves), 0, waves};
+}
 
 // circle_fitting.py:35-54.  Uniform result in every thread.
 template <int NW, class View>
@@ -395,7 +410,9 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     if (P.n < 3)
         return PCFIT_ST_SPARSE;
     const double n = (double)P.n;
-    const bool lead = threadIdx.x < WAVE;
+    const int owner = red.owner();
+    red.next_owner();
+    const bool lead = (int)(threadIdx.x >> 6) == owner;
     double m[5];   // sum of u^2, v^2, u v, u z, v z about the mean (z = u^2 + v^2)
     double mx = 0.0, my = 0.0;
     // the power sums about the slice's first point: they came with the loads, or (a slice that is streamed) a
@@ -417,7 +434,7 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
             q[k] = P.m9[k];
     }
     double *tot = red.totals(1);
-    block_reduce_to_lds<NS, false, NW, false>(q, 0.0, red.scratch(), tot);
+    block_reduce_to_lds<NS, false, NW, false>(q, 0.0, red.scratch(), tot, owner);
     if (lead) {
         const double su = tot[0], sv = tot[1], suu = tot[2], sz = tot[3], suv = tot[4], suz = tot[5], svz = tot[6];
         const double svv = sz - suu;
@@ -438,7 +455,7 @@ __device__ __forceinline__ int kasa_slice(const View &P, RedCtx &red, double out
     double *share = red.share();
     if (lead) {
         const int st = kasa_from_moments(m, mx, my, n, out);
-        if (threadIdx.x == 0) {
+        if ((threadIdx.x & 63) == 0) {
             share[0] = out[0];
             share[1] = out[1];
             share[2] = out[2];
@@ -567,7 +584,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);
-            block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot);
+            block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot, red.owner());
             ph.mark(3);
             return;
         }
@@ -579,39 +596,48 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false, std::false_type{}); });
         P.ragged_group(ragged);
         ph.mark(2);
-        block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot);
+        block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot, red.owner());
         ph.mark(3);
     };
 
     // (one call site for the sweep: its body is the bulk of the kernel's code)
     // The loop between the sweeps - 3x3 solves, the stopping rules, the model of the last step: several hundred
-    // instructions on values every thread would hold alike - runs on the first wave only.  The others wait at
-    // the barrier for the next candidate (in the end: for the result), their SIMDs free for the workgroup next
-    // door.
-    LmState st;
-    lm_begin(st, par, prm);
-    if (st.done) {                                  // (max_iter <= 0: the start is the result)
-        lm_finish(st, par, iters);
-        reach[0] = reach[1] = 0.0;
-        return false;
-    }
+    // instructions on values every thread would hold alike - runs on one wave, another one after every sweep
+    // (RedCtx::owner), which finds the loop's state in LDS where the last one left it.  The others wait at the
+    // barrier for the next candidate (in the end: for the result), their SIMDs free for the workgroup next door.
     double *share = red.share();
+    double *state = red.state();
     int32_t *ishare = reinterpret_cast<int32_t *>(share + 10);
-    double tx = st.tx, ty = st.ty, tr = st.tr;
+    {
+        LmState st;
+        lm_begin(st, par, prm);
+        if (st.done) {                              // (max_iter <= 0: the start is the result)
+            lm_finish(st, par, iters);
+            reach[0] = reach[1] = 0.0;
+            return false;
+        }
+        if (threadIdx.x == 0)
+            lm_state_store(st, state);              // (read after the first sweep's barrier)
+    }
+    double tx = par[0], ty = par[1], tr = par[2];
     int into = 0;
     bool done = false;
     bool first_sweep = true;
     while (!done) {
+        const int owner = red.owner();              // the wave that forms this sweep's totals and takes the step
         if (first_sweep)
             sweep(tx, ty, tr, red.totals(into), std::false_type{});
         else
             sweep(tx, ty, tr, red.totals(into), std::true_type{});
-        if (threadIdx.x < WAVE) {
+        red.next_owner();
+        if ((int)(threadIdx.x >> 6) == owner) {
+            LmState st;
+            lm_state_load(st, state);
             // (a short-form sweep that met a point it is not made for says so in place of the smallest distance)
             const bool again = !general && red.totals(into)[12] == -inf;
             if (!again)
                 lm_step<RED_AREA, true>(st, prm, red.totals(0), into, !general && !first_sweep);
-            if (threadIdx.x == 0) {
+            if ((threadIdx.x & 63) == 0) {
                 ishare[7] = again ? 1 : 0;
                 share[0] = st.tx;
                 share[1] = st.ty;
@@ -633,8 +659,10 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     ishare[5] = r4[3];
                     ishare[6] = st.cur >= 0 ? 1 : 0;
                 }
+                if (!again)
+                    lm_state_store(st, state);
             }
-            }
+        }
         __syncthreads();
         if (ishare[7]) {
             general = true;                         // the same sweep once more, in the general form
@@ -667,7 +695,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (PT_L == 10 ? 3 : 2)) void kasa_kernel(c
                                                         int32_t *__restrict__ status)
 {
     __shared__ double lds[RED_SIZE];
-    RedCtx red{lds, 0};
+    RedCtx red = make_red(lds);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
@@ -692,7 +720,7 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void lm_kernel(const double *__restri
     __shared__ double lds[RED_SIZE];
     Phase ph;
     ph.init();
-    RedCtx red{lds, 0};
+    RedCtx red = make_red(lds);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
@@ -724,7 +752,7 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_kernel(const double *__restr
     __shared__ double lds[RED_SIZE];
     Phase ph;
     ph.init();
-    RedCtx red{lds, 0};
+    RedCtx red = make_red(lds);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
@@ -1000,7 +1028,7 @@ __global__ __launch_bounds__(FIT_BLOCK, (GIVEN ? 4 : !WITH_LM && PT_L == 10 ? 3 
     __shared__ int edges_off;           // set when the edges are not uniformly spaced
     Phase ph;
     ph.init();
-    RedCtx red{lds, 0};
+    RedCtx red = make_red(lds);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;

@@ -176,6 +176,31 @@ __device__ __forceinline__ void lm_begin(LmState &st, const double par[3], const
 
 __device__ __forceinline__ int lm_into(const LmState &st) { return st.cur == 0 ? 1 : 0; }
 
+// The state as LM_STATE_DOUBLES doubles: fit.hip keeps it in LDS between the sweeps, where the wave that takes the
+// next step finds it.
+constexpr int LM_STATE_DOUBLES = 16;
+__device__ __forceinline__ void lm_state_store(const LmState &st, double *p)
+{
+    p[0] = st.cx; p[1] = st.cy; p[2] = st.rad;
+    p[3] = st.tx; p[4] = st.ty; p[5] = st.tr;
+    p[6] = st.lam; p[7] = st.prev; p[8] = st.min_ri; p[9] = st.max_ri;
+    p[10] = st.step[0]; p[11] = st.step[1]; p[12] = st.step[2];
+    int32_t *q = reinterpret_cast<int32_t *>(p + 13);
+    q[0] = st.it; q[1] = st.acc_steps; q[2] = st.n_first; q[3] = st.n_sweeps; q[4] = st.cur;
+    q[5] = (st.first ? 1 : 0) | (st.done ? 2 : 0) | (st.regular ? 4 : 0);
+}
+
+__device__ __forceinline__ void lm_state_load(LmState &st, const double *p)
+{
+    st.cx = p[0]; st.cy = p[1]; st.rad = p[2];
+    st.tx = p[3]; st.ty = p[4]; st.tr = p[5];
+    st.lam = p[6]; st.prev = p[7]; st.min_ri = p[8]; st.max_ri = p[9];
+    st.step[0] = p[10]; st.step[1] = p[11]; st.step[2] = p[12];
+    const int32_t *q = reinterpret_cast<const int32_t *>(p + 13);
+    st.it = q[0]; st.acc_steps = q[1]; st.n_first = q[2]; st.n_sweeps = q[3]; st.cur = q[4];
+    st.first = (q[5] & 1) != 0; st.done = (q[5] & 2) != 0; st.regular = (q[5] & 4) != 0;
+}
+
 // Whether the candidate p + d (d = st.step, solved from H, g at the current parameters p in hg) can be taken as
 // the loop's result without a sweep: the candidate is accepted, and every candidate after it is rejected.
 // Needs hg from a sweep that found every point regular (distance above zero, residual within the Huber

@@ -432,10 +432,13 @@ __device__ __forceinline__ double wave_min(double v)
 // second one is left out: the totals are written by lanes of the first wave, which
 // may read them at once (LDS operations of one wave complete in order); any other
 // wave has to pass a barrier of the caller's first.
+// `owner`: the wave whose lanes form the totals (and may read them at once when END_BARRIER is left out).
 template <int K, bool WITH_MIN, int NW, bool END_BARRIER = true>
-__device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, double *scratch, double *dst)
+__device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, double *scratch, double *dst,
+                                                    int owner = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = (int)threadIdx.x - owner * 64;          // lanes 0, 1, ... of the owning wave
     rs_steps<K, 32>(v, lane);
     bool valid = true;
     const int k = rs_index<K, 32>(lane, valid);
@@ -446,17 +449,17 @@ __device__ __forceinline__ void block_reduce_to_lds(double (&v)[K], double low, 
     if (WITH_MIN && lane == 0)
         scratch[K * 16 + wave] = low;
     __syncthreads();
-    if (threadIdx.x < K) {
+    if (tid >= 0 && tid < K) {
         double part[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++)
-            part[w] = scratch[threadIdx.x * 16 + w];
+            part[w] = scratch[tid * 16 + w];
         double s = part[0];
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s += part[w];
-        dst[threadIdx.x] = s;
-    } else if (WITH_MIN && threadIdx.x == K) {
+        dst[tid] = s;
+    } else if (WITH_MIN && tid == K) {
         double s = scratch[K * 16];
 #pragma unroll
         for (int w = 1; w < NW; w++)
@@ -476,9 +479,10 @@ __device__ __forceinline__ double wave_max(double v)
 // from the AT-th on follow them (sum k at dst[k + 2]).  scratch: (K + 2) * 16 doubles.
 template <int K, int NW, int AT = K, bool END_BARRIER = true>
 __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low, double high, double *scratch,
-                                                     double *dst)
+                                                     double *dst, int owner = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = (int)threadIdx.x - owner * 64;
     rs_steps<K, 32>(v, lane);
     bool valid = true;
     const int k = rs_index<K, 32>(lane, valid);
@@ -491,23 +495,23 @@ __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low,
         scratch[(K + 1) * 16 + wave] = high;
     }
     __syncthreads();
-    if (threadIdx.x < K) {
+    if (tid >= 0 && tid < K) {
         double part[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++)
-            part[w] = scratch[threadIdx.x * 16 + w];
+            part[w] = scratch[tid * 16 + w];
         double s = part[0];
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s += part[w];
-        dst[threadIdx.x < AT ? threadIdx.x : threadIdx.x + 2] = s;
-    } else if (threadIdx.x == K) {
+        dst[tid < AT ? tid : tid + 2] = s;
+    } else if (tid == K) {
         double s = scratch[K * 16];
 #pragma unroll
         for (int w = 1; w < NW; w++)
             s = fmin(s, scratch[K * 16 + w]);
         dst[AT] = s;
-    } else if (threadIdx.x == K + 1) {
+    } else if (tid == K + 1) {
         double s = scratch[(K + 1) * 16];
 #pragma unroll
         for (int w = 1; w < NW; w++)
