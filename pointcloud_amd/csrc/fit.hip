@@ -381,9 +381,9 @@ constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE
 // lets a reduction do without a barrier on entry.
 // Which wave does the work that falls to one wave - the circle from the Kasa moments, every step of the LM loop
 // between two sweeps (several hundred dependent instructions each): a different wave each time (turn), starting
-// from a wave that differs from workgroup to workgroup.  The waves of a workgroup sit on different SIMDs; with one
-// fixed wave for all of it, that wave's SIMD - shared with the same wave of the CU's other workgroup - carried a
-// third more instructions than the other three and set the pace.
+// from a wave that differs from workgroup to workgroup.  The four waves of a workgroup sit on the four SIMDs of
+// its CU (the first wave on any of them: tools/ubench/wave_simd.hip); with one fixed wave for all of this work
+// that wave's SIMD carried a third more instructions for the slice than the other three.
 struct RedCtx {
     double *lds;
     int count;
