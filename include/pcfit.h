@@ -262,6 +262,10 @@ int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *o
  * -1 = default) names a hull vertex, at that vertex.  n_hull[s] = 0 and
  * status 2 when the unique points have no 2-D variation; status 1 when fewer
  * than 3 points. */
+/* In the host-pointer forms below (pcfit_unique_hull_batch, pcfit_hybrid_batch) a hull_start entry of
+ * PCFIT_HULL_START_QHULL asks for the vertex scipy.spatial.ConvexHull(xy).vertices lists first
+ * (circle_fitting.py:189-190), found by pcfit_qhull_order_batch on the host. */
+#define PCFIT_HULL_START_QHULL (-2)
 size_t pcfit_unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices);
 int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                 int64_t max_slice_len, double *ux, double *uy, int64_t *n_unique,
@@ -315,6 +319,19 @@ int pcfit_unique_hull_batch(const double *x, const double *y, const int64_t *off
                             const int64_t *hull_start);
 int pcfit_ovality_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                         const double *cxcyr, double *scal, double *dev_uniform, int64_t grid_len);
+
+/* The order of `ConvexHull(xy).vertices` (circle_fitting.py:189-190: the RANSAC candidates in the order the
+ * sampled indices refer to).  scipy walks Qhull's facet list from its head, so the first vertex depends on
+ * Qhull's incremental construction; this call replays that construction (libqhull 2020.2 under scipy's
+ * options, 2-D, points in general position) on n_threads host cores (0 = one per core, at most 16) for
+ * slices of distinct points laid out like the ux / uy / n_unique of pcfit_unique_hull_batch (n_unique NULL:
+ * every slice is full).  start[s]: index of the first vertex in the slice's array, -1 when there is no hull.
+ * Nullable: sure[s] = 0 when a decision fell inside Qhull's roundoff bands (nearly collinear hull points,
+ * points on an edge of the hull: Qhull would merge facets there, which is not replayed) and start[s] is a
+ * best effort; walk (capacity as ux) + n_walk[s]: all vertices in scipy's order.  No GPU work. */
+int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
+                            int64_t n_slices, int32_t n_threads, int64_t *start, uint8_t *sure, int64_t *walk,
+                            int64_t *n_walk);
 
 /* _has_enough_2d_variation (circle_fitting.py:14-19) per slice: ok[s] = 1 when
  * the second singular value of the centred points exceeds eps*(first + eps). */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pcfit_bin_slices": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pcfit_unique_hull_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_ovality_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64]),
+    "pcfit_qhull_order_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "pcfit_rank_check_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
@@ -275,6 +276,35 @@ def bin_slices(points, z_lo, z_hi, want_perm=True):
     return offsets, xo[:t], yo[:t], (perm[:t] if want_perm else None)
 
 
+HULL_START_QHULL = -2      # PCFIT_HULL_START_QHULL
+
+
+def _hull_starts(hull_start, S):
+    """None, per-slice indices, or "qhull": the vertex scipy's ConvexHull lists first, for every slice."""
+    if hull_start is None:
+        return None
+    if isinstance(hull_start, str):
+        if hull_start != "qhull":
+            raise ValueError('hull_start: indices, None or "qhull"')
+        return np.full(S, HULL_START_QHULL, np.int64)
+    return _arr(hull_start, np.int64)
+
+
+def qhull_order_batch(ux, uy, offsets=None, n_unique=None, n_threads=0, want_walk=True):
+    """The order of ``scipy.spatial.ConvexHull(xy).vertices`` for slices of distinct points (host cores):
+    start, sure, and with want_walk the whole vertex lists (walk, n_walk)."""
+    ux, uy, offsets = as_csr(ux, uy, offsets)
+    S = offsets.size - 1
+    nu = None if n_unique is None else _arr(n_unique, np.int64)
+    start = np.full(S, -1, np.int64)
+    sure = np.zeros(S, np.uint8)
+    walk = np.zeros(max(ux.size, 1), np.int64) if want_walk else None
+    n_walk = np.zeros(S, np.int64)
+    check(lib().pcfit_qhull_order_batch(_p(ux), _p(uy), _p(offsets), _p(nu), S, int(n_threads), _p(start), _p(sure),
+                                        _p(walk), _p(n_walk)))
+    return dict(start=start, sure=sure.astype(bool), walk=walk, n_walk=n_walk, offsets=offsets)
+
+
 def unique_hull_batch(x, y, offsets=None, hull_start=None):
     x, y, offsets = as_csr(x, y, offsets)
     S = offsets.size - 1
@@ -283,7 +313,7 @@ def unique_hull_batch(x, y, offsets=None, hull_start=None):
     hidx = np.zeros(max(x.size, 1), np.int64)
     nh = np.zeros(S, np.int64)
     status = np.zeros(S, np.int32)
-    hs = None if hull_start is None else _arr(hull_start, np.int64)
+    hs = _hull_starts(hull_start, S)
     check(lib().pcfit_unique_hull_batch(_p(x), _p(y), _p(offsets), S, _p(ux), _p(uy), _p(nu), _p(hidx), _p(nh),
                                         _p(status), _p(hs)))
     return dict(ux=ux, uy=uy, n_unique=nu, hull_idx=hidx, n_hull=nh, status=status, offsets=offsets)
@@ -341,7 +371,7 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
     K = int(max(1024, min(OV_CAP, longest) if use_hull else longest))
     dev = np.full((S, K), np.nan) if want_profile else None
     rr = None if r_range is None else _arr(r_range, np.float64)
-    hs = None if hull_start is None else _arr(hull_start, np.int64)
+    hs = _hull_starts(hull_start, S)
     check(lib().pcfit_hybrid_batch(_p(x), _p(y), _p(offsets), S, inlier_tol, max_trials, min_inliers_frac, _p(rr),
                                    huber_delta, 1 if use_hull else 0, _p(hs), int(seed), _p(status), _p(fit), _p(ux),
                                    _p(uy), _p(n_unique), _p(cand_off), _p(cx_), _p(cy_), _p(mask), _p(radius),
