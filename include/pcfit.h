@@ -333,6 +333,14 @@ int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *o
                             int64_t n_slices, int32_t n_threads, int64_t *start, uint8_t *sure, int64_t *walk,
                             int64_t *n_walk);
 
+/* Where the hull walks of the hybrid chain start when the caller names no hull_start (and in the scan forms,
+ * which take none): 0 (default) = at the lexicographic minimum, 1 = where scipy's ConvexHull starts, as
+ * pcfit_qhull_order_batch finds it - the candidates then are circle_fitting.py:189-192's `xy[hull.vertices]`
+ * element for element, at the price of bringing the distinct points of every slice back to the host and one
+ * pass of the host cores over them.  A setting of the process, read at the start of a call. */
+int pcfit_set_hull_order(int32_t order);
+int pcfit_get_hull_order(int32_t *order);
+
 /* _has_enough_2d_variation (circle_fitting.py:14-19) per slice: ok[s] = 1 when
  * the second singular value of the centred points exceeds eps*(first + eps). */
 int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double eps,

@@ -7,8 +7,9 @@ points the reference uses (``np.sum`` pairwise sums, ``np.linalg.solve`` for
 because those define the reference's bits.  Only the convex hull differs: the
 reference calls Qhull through scipy, this file uses a monotone chain with an
 exact orientation test and starts the counter-clockwise walk at the
-lexicographically smallest vertex (Qhull's start vertex follows its internal
-facet list and is not reproduced).
+lexicographically smallest vertex; where Qhull's own start vertex is wanted
+(``hull_start="qhull"``) it comes from oracle/qhull2d.py, which restates
+Qhull's construction.
 
 Parity status: pinned by tests/golden/*.npz, which hold outputs of the real
 reference recorded by tests/golden/gen_golden.py in the build container.
@@ -274,8 +275,9 @@ def hybrid_fit(points_xyz, z_elevation, z_tolerance, inlier_tol=0.5, max_trials=
                min_inliers_frac=0.1, r_range=None, huber_delta=1.0,
                use_hull_vertices_only=True, hull_start=None):
     """mask -> unique -> rank check -> hull -> RANSAC -> Kasa -> LM.
-    circle_fitting.py:146-232.  ``hull_start`` (an index into the unique array)
-    rotates the candidate order, to replay Qhull's start vertex in tests."""
+    circle_fitting.py:146-232.  ``hull_start`` (an index into the unique array,
+    or "qhull" for the vertex ``ConvexHull(xy).vertices`` lists first) rotates
+    the candidate order."""
     points_xyz = np.asarray(points_xyz)
     if points_xyz.ndim != 2 or points_xyz.shape[1] != 3:
         raise ValueError("points_xyz must be (N,3)")
@@ -290,7 +292,12 @@ def hybrid_fit(points_xyz, z_elevation, z_tolerance, inlier_tol=0.5, max_trials=
     cand = None
     if xy.shape[0] >= 3 and has_2d_variation(xy):
         verts = hull_ccw(xy)
-        if hull_start is not None:
+        if isinstance(hull_start, str):
+            from . import qhull2d
+            order, _ = qhull2d.vertices(xy)
+            if order is not None:
+                verts = rotate_to(verts, order[0])
+        elif hull_start is not None:
             verts = rotate_to(verts, hull_start)
         if use_hull_vertices_only and verts.size >= 3:
             cand = xy[verts]
@@ -429,7 +436,12 @@ def residual_profile_at_z(points_xyz, res_fit, z_elevation, z_tolerance, use_hul
     used = xy
     if use_hull_vertices and has_2d_variation(xy):
         verts = hull_ccw(xy)
-        if hull_start is not None:
+        if isinstance(hull_start, str):
+            from . import qhull2d
+            order, _ = qhull2d.vertices(xy)
+            if order is not None:
+                verts = rotate_to(verts, order[0])
+        elif hull_start is not None:
             verts = rotate_to(verts, hull_start)
         if verts.size >= 3:
             used = xy[verts]

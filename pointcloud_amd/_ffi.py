@@ -89,6 +89,8 @@ SIGNATURES = {
     "pcfit_unique_hull_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_ovality_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64]),
     "pcfit_qhull_order_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "pcfit_set_hull_order": (C.c_int, [_i32]),
+    "pcfit_get_hull_order": (C.c_int, [_vp]),
     "pcfit_rank_check_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
     "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
@@ -303,6 +305,18 @@ def qhull_order_batch(ux, uy, offsets=None, n_unique=None, n_threads=0, want_wal
     check(lib().pcfit_qhull_order_batch(_p(ux), _p(uy), _p(offsets), _p(nu), S, int(n_threads), _p(start), _p(sure),
                                         _p(walk), _p(n_walk)))
     return dict(start=start, sure=sure.astype(bool), walk=walk, n_walk=n_walk, offsets=offsets)
+
+
+def set_hull_order(order):
+    """Where hull walks start when no hull_start is given: "canonical" (the lexicographic minimum, default)
+    or "qhull" (where scipy's ConvexHull starts; costs a host pass over every slice's distinct points)."""
+    check(lib().pcfit_set_hull_order({"canonical": 0, "qhull": 1}[order]))
+
+
+def get_hull_order():
+    v = np.zeros(1, np.int32)
+    check(lib().pcfit_get_hull_order(_p(v)))
+    return ("canonical", "qhull")[int(v[0])]
 
 
 def unique_hull_batch(x, y, offsets=None, hull_start=None):

@@ -96,14 +96,15 @@ class CylinderAnalyzer:
         return result, cand, (cx, cy, R), ov, edge
 
     # ------------------------------------------------------------------ reference API
-    def process_slice(self, points: np.ndarray, z_center: float, *, hull_start: Optional[int] = None
+    def process_slice(self, points: np.ndarray, z_center: float, *, hull_start=None
                       ) -> Tuple[dict, "pd.DataFrame", str]:  # noqa: F821
-        """Process a single slice of points (reference: analyzer.py:46-129)."""
+        """Process a single slice of points (reference: analyzer.py:46-129).  ``hull_start``: None, an index
+        or "qhull", as in utils.circle_fitting.fit_circle_hybrid_at_z."""
         import pandas as pd
 
         if not isinstance(points, _ffi.DeviceScan):
             points = np.asarray(points, float)
-        hs = None if hull_start is None else np.array([hull_start], np.int64)
+        hs = hull_start if hull_start is None or isinstance(hull_start, str) else np.array([hull_start], np.int64)
         dz = self.config.z_step / 2.0
         offsets, x, y, _ = _ffi.bin_slices(points, np.array([z_center - dz]), np.array([z_center + dz]),
                                            want_perm=False)

@@ -540,6 +540,30 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
     return PCFIT_OK;
 }
 
+// hull_start entries of PCFIT_HULL_START_QHULL: the walks of those slices are turned to the vertex that Qhull's
+// construction leaves first, replayed on host cores from the distinct points (which come back for it).
+static int apply_qhull_starts(const int64_t *hull_start, const int64_t *offsets, const int64_t *n_unique, int64_t S,
+                              int64_t total, const double *dux, const double *duy, const int64_t *doff,
+                              const int64_t *dnh, int64_t *dhi, hipStream_t st)
+{
+    bool any = false;
+    for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
+    if (!any || total <= 0) return PCFIT_OK;
+    std::vector<double> hx((size_t)total), hy((size_t)total);
+    PCFIT_HIP(hipMemcpyAsync(hx.data(), dux, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    PCFIT_HIP(hipMemcpyAsync(hy.data(), duy, (size_t)total * 8, hipMemcpyDeviceToHost, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    std::vector<int64_t> start((size_t)S, -1);
+    PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), offsets, n_unique, S, 0, hull_start, start.data(), nullptr, nullptr,
+                               nullptr));
+    DevBuf dstart, dtmp;
+    PCFIT_TRY(dstart.upload(start.data(), (size_t)S * 8, st));
+    PCFIT_TRY(dtmp.alloc((size_t)total * 8));
+    PCFIT_TRY(hull_rotate_dev(doff, dnh, dstart.as<int64_t>(), S, dhi, dtmp.as<int64_t>(), st));
+    PCFIT_HIP(hipStreamSynchronize(st));               // start (pageable) and the buffers end with this call
+    return PCFIT_OK;
+}
+
 // ------------------------------------------------- host-pointer entry points
 PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                       double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull,
@@ -568,9 +592,12 @@ PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const in
                                           dux.as<double>(), duy.as<double>(), dnu.as<int64_t>(), dhi.as<int64_t>(),
                                           dnh.as<int64_t>(), dst.as<int32_t>(), dhs.as<int64_t>(), dws.p, dws.bytes,
                                           st));
+    PCFIT_TRY(dnu.download(n_unique, n_slices * 8, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    PCFIT_TRY(apply_qhull_starts(hull_start, offsets, n_unique, n_slices, total, dux.as<double>(), duy.as<double>(),
+                                 doff.as<int64_t>(), dnh.as<int64_t>(), dhi.as<int64_t>(), st));
     PCFIT_TRY(dux.download(ux, total * 8, st));
     PCFIT_TRY(duy.download(uy, total * 8, st));
-    PCFIT_TRY(dnu.download(n_unique, n_slices * 8, st));
     PCFIT_TRY(dhi.download(hull_idx, total * 8, st));
     PCFIT_TRY(dnh.download(n_hull, n_slices * 8, st));
     PCFIT_TRY(dst.download(status, n_slices * 4, st));
@@ -700,6 +727,11 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     std::vector<char> hbuf;
 
     // 1. distinct points, rank check, hull
+    std::vector<int64_t> qhull_everywhere;
+    if (!hull_start && use_hull && hull_order_mode() == 1) {
+        qhull_everywhere.assign((size_t)S, PCFIT_HULL_START_QHULL);
+        hull_start = qhull_everywhere.data();
+    }
     DevBuf dux, duy, dhi, dhs, dws, d1;
     PCFIT_TRY(dux.alloc(total * 8));
     PCFIT_TRY(duy.alloc(total * 8));
@@ -722,6 +754,9 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     memcpy(n_unique, hbuf.data() + nu_at, (size_t)S * 8);
     memcpy(n_hull.data(), hbuf.data() + nh_at, (size_t)S * 8);
     memcpy(status, hbuf.data() + st1_at, (size_t)S * 4);
+    if (use_hull)
+        PCFIT_TRY(apply_qhull_starts(hull_start, offsets, n_unique, S, total, dux.as<double>(), duy.as<double>(), doffp,
+                                     dnh, dhi.as<int64_t>(), st));
 
     // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
     int64_t max_cand = 0;

@@ -14,6 +14,7 @@
 #include "pcfit_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <thread>
 #include <vector>
@@ -500,6 +501,9 @@ __global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restr
 
 }  // namespace
 
+static std::atomic<int> g_hull_order{0};
+int hull_order_mode() { return g_hull_order.load(std::memory_order_relaxed); }
+
 int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk)
@@ -559,4 +563,18 @@ PCFIT_API int pcfit_qhull_order_batch(const double *ux, const double *uy, const 
         set_error("qhull_order: %s", e.what());
         return PCFIT_ERR_INVALID;
     }
+}
+
+PCFIT_API int pcfit_set_hull_order(int32_t order)
+{
+    PCFIT_REQUIRE(order == 0 || order == 1, "set_hull_order: 0 (from the lexicographic minimum) or 1 (Qhull's)");
+    g_hull_order.store(order, std::memory_order_relaxed);
+    return PCFIT_OK;
+}
+
+PCFIT_API int pcfit_get_hull_order(int32_t *order)
+{
+    PCFIT_REQUIRE(order, "get_hull_order: null pointer");
+    *order = hull_order_mode();
+    return PCFIT_OK;
 }

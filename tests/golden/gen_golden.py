@@ -517,6 +517,31 @@ def g_year_export():
     save("year_export", **out)
 
 
+def g_qhull_order():
+    """What ``scipy.spatial.ConvexHull(xy).vertices`` (circle_fitting.py:189-190) returns for slices of many
+    kinds (oracle.qhull2d.make_case: inputs only): the first vertex, the count and a SHA-256 of the list."""
+    from scipy.spatial import ConvexHull
+    from oracle.qhull2d import KINDS, make_case
+    gen = np.random.default_rng(2024)
+    rows, first, count, digest = [], [], [], []
+    for r in range(60 * len(KINDS)):
+        kind = r % len(KINDS)
+        n, seed = int(gen.choice([4, 10, 30, 200, 1500, 8192])), int(gen.integers(1 << 30))
+        xy = make_case(KINDS[kind], n, seed)
+        if len(xy) < 3:
+            continue
+        try:
+            v = ConvexHull(xy).vertices.astype(np.int64)
+        except Exception:           # noqa: BLE001  (Qhull refuses flat input)
+            continue
+        rows.append([kind, n, seed, len(xy)])
+        first.append(int(v[0]))
+        count.append(len(v))
+        digest.append(sha(v))
+    save("qhull_order", kinds=np.array(KINDS), cases=np.array(rows, np.int64), first=np.array(first, np.int64),
+         count=np.array(count, np.int64), sha=np.array(digest))
+
+
 if __name__ == "__main__":
     only = sys.argv[2:]
     if only:
@@ -533,3 +558,4 @@ if __name__ == "__main__":
     g_analyzer()
     g_long_slices()
     g_year_export()
+    g_qhull_order()

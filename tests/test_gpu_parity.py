@@ -113,6 +113,65 @@ def test_unique_hull_hybrid_golden():
         assert rel(hy["fit"][0], g[f"fit{i}"]) < 1e-9
 
 
+def test_hybrid_in_qhulls_order_is_the_reference_without_hints():
+    """hull_start="qhull": the library finds the vertex scipy's ConvexHull lists first by itself; candidates,
+    inlier mask and fit are then what the reference returned (hull_hybrid.npz, long_slices.npz), and the hull
+    walk is ConvexHull(xy).vertices element for element."""
+    from pointcloud_amd.utils import circle_fitting as CF
+    g = load_golden("hull_hybrid")
+    xs, ys, off = [], [], [0]
+    for i in range(10):
+        pts = g[f"pts{i}"]
+        o, x, y, _ = F.bin_slices(pts, [-0.5], [0.5])
+        xs.append(x), ys.append(y), off.append(off[-1] + len(x))
+        h = F.unique_hull_batch(x, y, o, hull_start="qhull")
+        q = g[f"qhull{i}"]
+        assert np.array_equal(h["hull_idx"][:int(h["n_hull"][0])], q), i
+        res = CF.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=800, hull_start="qhull")
+        assert (res is not None) == bool(g[f"ok{i}"]), i
+        if res is not None:
+            assert np.array_equal(res["candidates_xy"], g[f"cand{i}"]) and np.array_equal(res["inlier_mask"], g[f"mask{i}"])
+            assert rel([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"]) < 1e-9
+    # the ten slices as one batch, some in Qhull's order, some from their lexicographic minimum, one from a named vertex
+    x, y, off = np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64)
+    want = np.array([F.HULL_START_QHULL, -1, F.HULL_START_QHULL, int(g["qhull3"][2]), -1, F.HULL_START_QHULL,
+                     F.HULL_START_QHULL, -1, F.HULL_START_QHULL, F.HULL_START_QHULL], np.int64)
+    h = F.unique_hull_batch(x, y, off, hull_start=want)
+    for i in range(10):
+        q = g[f"qhull{i}"]
+        walk = h["hull_idx"][off[i]:off[i] + int(h["n_hull"][i])]
+        if len(q) == 0:
+            continue
+        first = {F.HULL_START_QHULL: int(q[0]), -1: 0}.get(int(want[i]), int(want[i]))
+        assert walk[0] == first and same_cycle(walk, q), i
+    # the process-wide setting does the same for calls that name no start (and for the scan forms)
+    hy_named = F.hybrid_batch(x, y, off, max_trials=800, hull_start="qhull", want_profile=False)
+    F.set_hull_order("qhull")
+    try:
+        assert F.get_hull_order() == "qhull"
+        hy_set = F.hybrid_batch(x, y, off, max_trials=800, want_profile=False)
+        pts = np.concatenate([np.column_stack([xs[i], ys[i], np.full(len(xs[i]), 2.0 * i)]) for i in range(10)])
+        zc = 2.0 * np.arange(10)
+        sc = F.scan_hybrid_batch(pts, zc - 0.5, zc + 0.5, max_trials=800, want_profile=False)
+    finally:
+        F.set_hull_order("canonical")
+    assert F.get_hull_order() == "canonical"
+    for k in ("status", "cand_offsets", "cand_x", "cand_y", "mask", "fit"):
+        assert np.array_equal(hy_named[k], hy_set[k], equal_nan=k == "fit"), k
+        assert np.array_equal(hy_named[k], sc[k], equal_nan=k == "fit"), k
+    for i in range(10):
+        c0, c1 = hy_named["cand_offsets"][i], hy_named["cand_offsets"][i + 1]
+        if bool(g[f"ok{i}"]):
+            assert np.array_equal(np.stack([hy_named["cand_x"][c0:c1], hy_named["cand_y"][c0:c1]], 1), g[f"cand{i}"])
+            assert np.array_equal(hy_named["mask"][c0:c1], g[f"mask{i}"])
+    g = load_golden("long_slices")
+    for i, (n, seed, outlier, dup) in enumerate(g["cases"]):
+        pts = R.make_slab(int(n), int(seed), float(outlier), int(dup))
+        res = CF.fit_circle_hybrid_at_z(pts, 0.0, 0.5, max_trials=600, hull_start="qhull")
+        assert np.array_equal(res["candidates_xy"], g[f"cand{i}"]) and np.array_equal(res["inlier_mask"], g[f"mask{i}"])
+        assert rel([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"]) < 1e-9
+
+
 def _ring50k():
     gen = np.random.default_rng(64)
     th = gen.uniform(0, 2 * np.pi, 50000)

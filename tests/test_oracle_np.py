@@ -96,6 +96,9 @@ def test_unique_hull_hybrid():
         assert np.array_equal(res["candidates_xy"], g[f"cand{i}"])
         assert np.array_equal(res["inlier_mask"], g[f"mask{i}"])
         assert close([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"], 1e-9)
+        # ... and with Qhull's construction restated instead of its first vertex handed over
+        res = R.hybrid_fit(pts, 0.0, 0.5, max_trials=800, hull_start="qhull")
+        assert np.array_equal(res["candidates_xy"], g[f"cand{i}"]) and np.array_equal(res["inlier_mask"], g[f"mask{i}"])
 
 
 def _sha(a):
