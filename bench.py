@@ -219,14 +219,26 @@ def extra_configs(L, dev, stream):
         for _ in range(3):
             res = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
         t_an = (time.perf_counter() - t_an) / 3
+        # the same with every hull walked from where scipy's ConvexHull starts (the distinct points of all windows
+        # come back to the host, whose cores replay Qhull's construction): the reference's candidates element
+        # for element
+        F.set_hull_order("qhull")
+        try:
+            t_q = time.perf_counter()
+            res_q = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
+            t_q = time.perf_counter() - t_q
+        finally:
+            F.set_hull_order("canonical")
     okw = res["status"] == 0
     out["hybrid_analysis_100M_points_2000_windows_resident"] = {
         "ms_per_analysis": t_an * 1e3, "points_per_s": n / t_an, "windows_fitted": int(okw.sum()),
         # (the reference fits the hull's vertices: with outliers beyond the ring that is the outliers' outline)
         "median_radius": float(np.median(res["fit"][okw, 2])) if okw.any() else None,
         "candidates_returned": int(res["cand_offsets"][-1]),
+        "ms_per_analysis_in_qhulls_vertex_order": t_q * 1e3,
+        "same_candidate_sets_in_qhulls_order": bool(np.array_equal(res["cand_offsets"], res_q["cand_offsets"])),
         "ms_upload_from_pageable_host_memory": t_up * 1e3, "upload_gb_per_s": host.nbytes / t_up / 1e9}
-    del host, res
+    del host, res, res_q
     # the passes over the binned scan: each reads x, y of every window member (16 B) once per sweep
     del xyz, ws
     torch.cuda.empty_cache()
