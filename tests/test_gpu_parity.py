@@ -452,6 +452,38 @@ def test_two_runs_are_bitwise_identical():
         assert np.array_equal(a[key], b[key], equal_nan=True), key
 
 
+def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
+    """set_hull_order("qhull"): the analyzer's candidates are the reference's `xy[hull.vertices]` in the
+    reference's order, so every slice - the three whose hull holds outliers included - has the reference's
+    boundary points, fit and metrics (tests/golden/analyzer.npz, recorded from the reference itself)."""
+    import pointcloud_amd as P
+    g = load_golden("analyzer")
+    pts = analyzer_points()
+    P.set_hull_order("qhull")
+    try:
+        res = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000)).analyze_with_progress(pts)
+    finally:
+        P.set_hull_order("canonical")
+    assert len(res) == int(g["n_results"])
+    mine = np.array([[r[k] for k in SCALARS] for r in res], dtype=float)
+    ref = g["scalars"]
+    exact = [SCALARS.index(k) for k in ("z_center", "z_low", "z_high", "n_points_slice", "n_edge", "cost",
+                                        "x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin")]
+    assert np.array_equal(mine[:, exact], ref[:, exact])
+    off = 0
+    for r, n in zip(res, g["bpts_len"]):
+        assert np.array_equal(np.array(r["boundary_points"]), g["bpts_cat"][off:off + n])    # same first vertex
+        off += n
+    fitc = [SCALARS.index(k) for k in ("cx", "cy", "R")]
+    dev = np.abs(mine[:, fitc] - ref[:, fitc]).max(axis=1) / ref[:, SCALARS.index("R")]
+    assert dev.max() < 1e-9, dev
+    for col in ("Rmax", "Rmin", "ovality_abs", "ovality_pct"):
+        c = SCALARS.index(col)
+        assert rel(mine[:, c], ref[:, c]) < 1e-7, col
+    c = SCALARS.index("k2_amp")
+    assert np.max(np.abs(mine[:, c] - ref[:, c])) < 1e-9
+
+
 # ------------------------------------------------------------------ drop-in layer
 SCALARS = ["z_center", "z_low", "z_high", "n_points_slice", "n_edge", "cx", "cy", "R", "Rmax", "Rmin",
            "x_at_Rmax", "y_at_Rmax", "x_at_Rmin", "y_at_Rmin", "ovality_abs", "ovality_pct", "k2_amp", "cost"]
