@@ -333,6 +333,24 @@ int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *o
                             int64_t n_slices, int32_t n_threads, int64_t *start, uint8_t *sure, int64_t *walk,
                             int64_t *n_walk);
 
+/* The same replay on the device, for slices that are there already (ux, uy, n_unique, n_hull as
+ * pcfit_unique_hull_batch_dev left them; select NULL = every slice, else only where select[s] ==
+ * PCFIT_HULL_START_QHULL): one workgroup per slice.  start[s] = the first vertex, -1 where there is no hull or
+ * the slice was not selected, PCFIT_QHULL_START_DEFER where the kernel met anything but the plain course of
+ * the construction (a decision inside Qhull's roundoff bands, a tie for the farthest point, a flat initial
+ * simplex, more than 511 facets alive at once) - those slices are for pcfit_qhull_order_batch.
+ * scratch: total_points * 8 bytes of device memory. */
+#define PCFIT_QHULL_START_DEFER (-3)
+int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
+                                const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total_points,
+                                void *scratch, size_t scratch_bytes, int64_t *start, void *stream);
+
+/* How many slices that kernel handed back since the last reset, by cause (out16[1..13]: flat simplex, simplex
+ * orientation, first partition near a threshold, tie for the farthest point, horizon near the threshold, more
+ * than 8 visible facets, new facets, facet slots, nearly collinear facets, partition near a threshold, pieces
+ * of an outside set, vertex count, steps).  For tools and tests; synchronises the device. */
+int pcfit_debug_qhull_reasons(int64_t *out16, int reset);
+
 /* Where the hull walks of the hybrid chain start when the caller names no hull_start (and in the scan forms,
  * which take none): 0 (default) = at the lexicographic minimum, 1 = where scipy's ConvexHull starts, as
  * pcfit_qhull_order_batch finds it - the candidates then are circle_fitting.py:189-192's `xy[hull.vertices]`

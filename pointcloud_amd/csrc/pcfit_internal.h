@@ -27,6 +27,12 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk);
 int hull_order_mode();         // pcfit_set_hull_order's value
+// qhull_dev.hip: the same replay on the device, one workgroup per slice; start[s] = QHULL_START_DEFER where the
+// host has to decide (anything but the plain course of the construction).  scratch: 2 * total int32 entries.
+constexpr int64_t QHULL_START_DEFER = -3;
+int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
+                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
+                    int64_t *start, hipStream_t st);
 int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const int64_t *start, int64_t n_slices,
                     int64_t *hull_idx, int64_t *tmp, hipStream_t st);
 

@@ -541,22 +541,54 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
 }
 
 // hull_start entries of PCFIT_HULL_START_QHULL: the walks of those slices are turned to the vertex that Qhull's
-// construction leaves first, replayed on host cores from the distinct points (which come back for it).
-static int apply_qhull_starts(const int64_t *hull_start, const int64_t *offsets, const int64_t *n_unique, int64_t S,
-                              int64_t total, const double *dux, const double *duy, const int64_t *doff,
-                              const int64_t *dnh, int64_t *dhi, hipStream_t st)
+// construction leaves first.  The construction is replayed on the device (qhull_dev.hip); the slices that
+// kernel hands back - decisions inside Qhull's roundoff bands, ties, capacities - have their distinct points
+// brought to the host and are replayed there (all selected slices with PCFIT_QHULL_ON_HOST=1 in the environment).
+static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
+                              const int64_t *n_unique, const int64_t *d_n_unique, int64_t S, int64_t total,
+                              const double *dux, const double *duy, const int64_t *doff, const int64_t *dnh,
+                              int64_t *dhi, hipStream_t st)
 {
     bool any = false;
     for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
     if (!any || total <= 0) return PCFIT_OK;
-    std::vector<double> hx((size_t)total), hy((size_t)total);
-    PCFIT_HIP(hipMemcpyAsync(hx.data(), dux, (size_t)total * 8, hipMemcpyDeviceToHost, st));
-    PCFIT_HIP(hipMemcpyAsync(hy.data(), duy, (size_t)total * 8, hipMemcpyDeviceToHost, st));
-    PCFIT_HIP(hipStreamSynchronize(st));
+    const char *env = std::getenv("PCFIT_QHULL_ON_HOST");
+    const bool on_host = env && env[0] == '1';
     std::vector<int64_t> start((size_t)S, -1);
-    PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), offsets, n_unique, S, 0, hull_start, start.data(), nullptr, nullptr,
-                               nullptr));
-    DevBuf dstart, dtmp;
+    DevBuf dstart, dscratch, dtmp;
+    PCFIT_TRY(dstart.alloc((size_t)S * 8));
+    if (!on_host) {
+        PCFIT_TRY(dscratch.alloc((size_t)total * 8));
+        PCFIT_TRY(qhull_start_dev(dux, duy, doff, d_n_unique, dnh, d_hull_start, S, total, dscratch.as<int>(),
+                                  dstart.as<int64_t>(), st));
+        PCFIT_TRY(dstart.download(start.data(), (size_t)S * 8, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+    } else {
+        for (int64_t s = 0; s < S; s++)
+            if (hull_start[s] == PCFIT_HULL_START_QHULL) start[s] = QHULL_START_DEFER;
+    }
+    // what the device handed back: those slices' points, packed, to the host replay
+    std::vector<int64_t> which, coff(1, 0);
+    for (int64_t s = 0; s < S; s++)
+        if (start[s] == QHULL_START_DEFER) {
+            start[s] = -1;
+            if (n_unique[s] < 3) continue;
+            which.push_back(s);
+            coff.push_back(coff.back() + n_unique[s]);
+        }
+    if (!which.empty()) {
+        std::vector<double> hx((size_t)coff.back()), hy((size_t)coff.back());
+        for (size_t k = 0; k < which.size(); k++) {
+            const int64_t s = which[k];
+            PCFIT_HIP(hipMemcpyAsync(hx.data() + coff[k], dux + offsets[s], (size_t)n_unique[s] * 8, hipMemcpyDeviceToHost, st));
+            PCFIT_HIP(hipMemcpyAsync(hy.data() + coff[k], duy + offsets[s], (size_t)n_unique[s] * 8, hipMemcpyDeviceToHost, st));
+        }
+        PCFIT_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> cstart(which.size(), -1);
+        PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), coff.data(), nullptr, (int64_t)which.size(), 0, nullptr,
+                                   cstart.data(), nullptr, nullptr, nullptr));
+        for (size_t k = 0; k < which.size(); k++) start[which[k]] = cstart[k];
+    }
     PCFIT_TRY(dstart.upload(start.data(), (size_t)S * 8, st));
     PCFIT_TRY(dtmp.alloc((size_t)total * 8));
     PCFIT_TRY(hull_rotate_dev(doff, dnh, dstart.as<int64_t>(), S, dhi, dtmp.as<int64_t>(), st));
@@ -594,8 +626,9 @@ PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const in
                                           st));
     PCFIT_TRY(dnu.download(n_unique, n_slices * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
-    PCFIT_TRY(apply_qhull_starts(hull_start, offsets, n_unique, n_slices, total, dux.as<double>(), duy.as<double>(),
-                                 doff.as<int64_t>(), dnh.as<int64_t>(), dhi.as<int64_t>(), st));
+    PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu.as<int64_t>(), n_slices, total,
+                                 dux.as<double>(), duy.as<double>(), doff.as<int64_t>(), dnh.as<int64_t>(),
+                                 dhi.as<int64_t>(), st));
     PCFIT_TRY(dux.download(ux, total * 8, st));
     PCFIT_TRY(duy.download(uy, total * 8, st));
     PCFIT_TRY(dhi.download(hull_idx, total * 8, st));
@@ -755,8 +788,8 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     memcpy(n_hull.data(), hbuf.data() + nh_at, (size_t)S * 8);
     memcpy(status, hbuf.data() + st1_at, (size_t)S * 4);
     if (use_hull)
-        PCFIT_TRY(apply_qhull_starts(hull_start, offsets, n_unique, S, total, dux.as<double>(), duy.as<double>(), doffp,
-                                     dnh, dhi.as<int64_t>(), st));
+        PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu, S, total, dux.as<double>(),
+                                     duy.as<double>(), doffp, dnh, dhi.as<int64_t>(), st));
 
     // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
     int64_t max_cand = 0;

@@ -1,0 +1,567 @@
+// The replay of Qhull's 2-D construction (see qhull_order.hip for what is replayed and why) on the device: one
+// workgroup per slice of distinct points.  The facet list, with Qhull's list moves, is kept by one thread in
+// LDS; the work that grows with the slice - the partition of the points into outside sets and of the outside
+// sets of visible facets among the two new facets, and the search of every set's farthest point - runs
+// across the workgroup.  The order of the points inside an outside set is not kept (it decides nothing but ties).
+// The kernel handles the plain course of the construction only: whenever a decision falls inside Qhull's
+// roundoff bands, a distance ties for the farthest point, the initial simplex is flat, or one of the fixed
+// capacities below runs out, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
+#include "pcfit_internal.h"
+
+namespace pcfit {
+__device__ unsigned long long g_qhull_reason[16];      // slices handed back, by cause (tools and tests)
+namespace {
+
+constexpr int QT = 256;          // threads of a workgroup
+constexpr int QF = 512;          // live facets of a slice (slot 0 is the list's tail)
+constexpr int QP = 6;            // pieces an outside set may lie in
+constexpr int QV = 8;            // visible facets of one insertion
+constexpr int64_t QHULL_DEFER = QHULL_START_DEFER;
+constexpr unsigned IDX_MASK = 0x7fffffffu;      // a piece's start; the top bit names the buffer it lies in
+
+struct Shared {
+    double n0[QF], n1[QF], off[QF];
+    int v0[QF], v1[QF], total[QF], far_idx[QF];
+    int plo[QF][QP], pcnt[QF][QP];
+    short nb0[QF], nb1[QF], prev[QF], next[QF], free_slot[QF];
+    unsigned char np[QF], top[QF], visible[QF];
+    // one insertion
+    int c0[QV * QP], c1[QV * QP];
+    double wave_d[2][QT / 64];
+    int wave_i[2][QT / 64], wave_tie[2][QT / 64];
+    int vis[QV], nvis, newf[2], apex, state, reason, n_free, head, nextf;
+    double red_d[QT / 64];
+    int red_i[QT / 64];
+    double thr[6];               // distround, minvisible, minoutside, distoutside, band, (unused)
+    int ext[4];
+};
+
+__device__ inline double plane_dist(const Shared &S, int f, double x, double y) { return S.off[f] + x * S.n0[f] + y * S.n1[f]; }
+
+__device__ inline void set_plane(Shared &S, int f, const double *x, const double *y)
+{
+    const int a = S.v0[f], b = S.v1[f];
+    const double nx = y[b] - y[a], ny = x[a] - x[b];
+    double norm = sqrt(nx * nx + ny * ny);
+    if (!S.top[f]) norm = -norm;
+    S.n0[f] = nx / norm;
+    S.n1[f] = ny / norm;
+    S.off[f] = -(x[a] * S.n0[f] + y[a] * S.n1[f]);
+}
+
+// qh_removefacet / qh_appendfacet on the list in LDS (one thread)
+__device__ inline void list_remove(Shared &S, int k)
+{
+    if (S.nextf == k) S.nextf = S.next[k];
+    if (S.head == k) { S.head = S.next[k]; S.prev[S.next[k]] = -1; }
+    else { S.next[S.prev[k]] = S.next[k]; S.prev[S.next[k]] = S.prev[k]; }
+}
+__device__ inline void list_append(Shared &S, int k)
+{
+    if (S.nextf == 0) S.nextf = k;
+    S.prev[k] = S.prev[0];
+    S.next[k] = 0;
+    if (S.head == 0) { S.head = k; S.prev[k] = -1; }
+    else S.next[S.prev[0]] = (short)k;
+    S.prev[0] = (short)k;
+}
+
+// first index of the least / greatest value over the workgroup (every thread gets the result)
+template <bool GREATEST>
+__device__ int block_arg_extreme(Shared &S, const double *c, int m)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = 0.0;
+    int at = -1;
+    for (int i = tid; i < m; i += QT) {
+        const double v = c[i];
+        if (at < 0 || (GREATEST ? v > best : v < best)) { best = v; at = i; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double ob = __shfl_xor(best, d);
+        const int oa = __shfl_xor(at, d);
+        if (oa >= 0 && (at < 0 || (GREATEST ? ob > best : ob < best) || (ob == best && oa < at))) { best = ob; at = oa; }
+    }
+    __syncthreads();
+    if (lane == 0) { S.red_d[wave] = best; S.red_i[wave] = at; }
+    __syncthreads();
+    best = S.red_d[0];
+    at = S.red_i[0];
+    for (int w = 1; w < QT / 64; w++) {
+        const double ob = S.red_d[w];
+        const int oa = S.red_i[w];
+        if (oa >= 0 && (at < 0 || (GREATEST ? ob > best : ob < best) || (ob == best && oa < at))) { best = ob; at = oa; }
+    }
+    return at;
+}
+
+// The farthest point of each of two classes, over what every thread has seen: (distance, point) per class in
+// far_d / far_i, and whether the greatest distance was met by more than one point.
+__device__ void block_far(Shared &S, double d0, int i0, double d1, int i1, double out_d[2], int out_i[2], int out_tie[2])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double d[2] = {d0, d1};
+    int at[2] = {i0, i1}, tie[2] = {0, 0};
+    for (int c = 0; c < 2; c++) {
+        for (int s = 32; s >= 1; s >>= 1) {
+            const double od = __shfl_xor(d[c], s);
+            const int oi = __shfl_xor(at[c], s), ot = __shfl_xor(tie[c], s);
+            if (oi >= 0) {
+                if (at[c] < 0 || od > d[c]) { d[c] = od; at[c] = oi; tie[c] = ot; }
+                else if (od == d[c] && oi != at[c]) tie[c] = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0)
+        for (int c = 0; c < 2; c++) { S.wave_d[c][wave] = d[c]; S.wave_i[c][wave] = at[c]; S.wave_tie[c][wave] = tie[c]; }
+    __syncthreads();
+    for (int c = 0; c < 2; c++) {
+        out_d[c] = 0.0;
+        out_i[c] = -1;
+        out_tie[c] = 0;
+        for (int w = 0; w < QT / 64; w++) {
+            const double od = S.wave_d[c][w];
+            const int oi = S.wave_i[c][w], ot = S.wave_tie[c][w];
+            if (oi < 0) continue;
+            if (out_i[c] < 0 || od > out_d[c]) { out_d[c] = od; out_i[c] = oi; out_tie[c] = ot; }
+            else if (od == out_d[c] && oi != out_i[c]) out_tie[c] = 1;
+        }
+    }
+}
+
+// where a thread's point goes in its class's run: runs of class 0 grow upwards from `lo`, runs of class 1
+// downwards from the piece's end (one LDS atomic per wave and class)
+__device__ inline int wave_slot(int *counter, bool mine)
+{
+    const unsigned long long votes = __builtin_amdgcn_ballot_w64(mine);
+    if (!votes) return 0;
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)votes) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(counter, __popcll(votes));
+    base = __shfl(base, leader);
+    return base + __popcll(votes & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
+                                                         const int64_t *__restrict__ offsets,
+                                                         const int64_t *__restrict__ n_unique,
+                                                         const int64_t *__restrict__ n_hull,
+                                                         const int64_t *__restrict__ select, int *__restrict__ buf_a,
+                                                         int *__restrict__ buf_b, int64_t *__restrict__ start)
+{
+    __shared__ Shared S;
+    const int64_t s = blockIdx.x, off = offsets[s];
+    const int tid = threadIdx.x;
+    if (select && select[s] != PCFIT_HULL_START_QHULL) {
+        if (tid == 0) start[s] = -1;
+        return;
+    }
+    const int64_t m64 = n_unique[s];
+    if (m64 < 3 || n_hull[s] < 3) {
+        if (tid == 0) start[s] = -1;
+        return;
+    }
+    if (m64 >= (1ll << 30)) {
+        if (tid == 0) start[s] = QHULL_DEFER;
+        return;
+    }
+    const int m = (int)m64;
+    const double *x = ux + off, *y = uy + off;
+    int *const bufs0 = buf_a + off, *const bufs1 = buf_b + off;
+
+    // qh_maxmin, qh_detroundoff, qh_maxsimplex
+    const int xlo = block_arg_extreme<false>(S, x, m), xhi = block_arg_extreme<true>(S, x, m);
+    const int ylo = block_arg_extreme<false>(S, y, m), yhi = block_arg_extreme<true>(S, y, m);
+    if (tid == 0) {
+        S.state = 0;
+        S.reason = 0;
+        const int ext[4] = {xlo, xhi, ylo, yhi};
+        const double ax = fmax(fabs(x[xlo]), fabs(x[xhi])), ay = fmax(fabs(y[ylo]), fabs(y[yhi]));
+        const double maxabs = fmax(ax, ay), sumabs = ax + ay;
+        const double maxwidth = fmax(x[xhi] - x[xlo], y[yhi] - y[ylo]);
+        const double eps = 2.220446049250313e-16;
+        const double distround = eps * (2 * fmin(sqrt(2.0) * maxabs, sumabs) * 1.01 + maxabs);
+        S.thr[0] = distround;
+        S.thr[1] = 2 * distround;                  // minvisible
+        S.thr[2] = 4 * distround;                  // minoutside
+        S.thr[3] = 8 * distround;                  // distoutside
+        S.thr[4] = 64 * distround + 8 * distround; // every threshold lies inside this band about zero
+        int minx = ext[0], maxx = ext[0];
+        for (int k = 0; k < 4; k++) {
+            if (x[ext[k]] > x[maxx]) maxx = ext[k];
+            if (x[ext[k]] < x[minx]) minx = ext[k];
+        }
+        int third = -1;
+        double bestdet = -1.0;
+        if (minx != maxx)
+            for (int k = 0; k < 4; k++) {
+                const int i = ext[k];
+                if (i == minx || i == maxx) continue;
+                const double det = fabs((x[minx] - x[i]) * (y[maxx] - y[i]) - (x[maxx] - x[i]) * (y[minx] - y[i]));
+                if (det > bestdet) { bestdet = det; third = i; }
+            }
+        const double target = (x[maxx] - x[minx]) * maxwidth, nearzero = 10 * (80 * sumabs * eps);
+        if (minx == maxx || third < 0 || bestdet < nearzero || bestdet / target < 1e-3)
+            { S.state = 2; S.reason = 1; }          // a flat simplex: Qhull's search of all points is the host's
+        else {
+            // qh_createsimplex, qh_initialhull
+            for (int k = 0; k < QF; k++) S.free_slot[k] = (short)(QF - 1 - k);      // slots QF-1 .. 1 (0 is the tail)
+            S.n_free = QF - 1;
+            S.head = S.nextf = 0;
+            S.prev[0] = -1;
+            S.next[0] = 0;
+            const int vs[3] = {third, maxx, minx};
+            int fs[3];
+            bool top = true;
+            for (int i = 0; i < 3; i++) {
+                const int f = S.free_slot[--S.n_free + 0];
+                fs[i] = f;
+                S.v0[f] = vs[i == 0 ? 1 : 0];
+                S.v1[f] = vs[i == 2 ? 1 : 2];
+                S.top[f] = top;
+                S.visible[f] = 0;
+                S.np[f] = 0;
+                S.total[f] = 0;
+                S.far_idx[f] = -1;
+                list_append(S, f);
+                top = !top;
+            }
+            S.nb0[fs[0]] = (short)fs[1]; S.nb1[fs[0]] = (short)fs[2];
+            S.nb0[fs[1]] = (short)fs[0]; S.nb1[fs[1]] = (short)fs[2];
+            S.nb0[fs[2]] = (short)fs[0]; S.nb1[fs[2]] = (short)fs[1];
+            const double cx = (x[minx] + x[maxx] + x[third]) / 3.0, cy = (y[minx] + y[maxx] + y[third]) / 3.0;
+            set_plane(S, fs[0], x, y);
+            if (plane_dist(S, fs[0], cx, cy) > 0)
+                for (int i = 0; i < 3; i++) S.top[fs[i]] = !S.top[fs[i]];
+            for (int i = 0; i < 3; i++) {
+                set_plane(S, fs[i], x, y);
+                if (!(plane_dist(S, fs[i], cx, cy) < -S.thr[4])) { S.state = 2; S.reason = 2; }
+            }
+            S.vis[0] = fs[0]; S.vis[1] = fs[1]; S.vis[2] = fs[2];
+            S.ext[0] = minx; S.ext[1] = maxx; S.ext[2] = third;
+            S.c0[0] = S.c0[1] = S.c0[2] = 0;
+        }
+    }
+    __syncthreads();
+    if (S.state == 2) {
+        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        return;
+    }
+    // qh_partitionall: every point to the first of the three facets it lies outside of (counts, then places)
+    {
+        const int f0 = S.vis[0], f1 = S.vis[1], f2 = S.vis[2];
+        const int e0 = S.ext[0], e1 = S.ext[1], e2 = S.ext[2];
+        const double thr = S.thr[3], band = S.thr[4];
+        double fd[3] = {0, 0, 0};
+        int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
+        bool doubt = false;
+        auto classify = [&](int i, double &d) -> int {
+            const double px = x[i], py = y[i];
+            for (int c = 0; c < 3; c++) {
+                d = plane_dist(S, c == 0 ? f0 : c == 1 ? f1 : f2, px, py);
+                if (fabs(d) < band) doubt = true;
+                if (d >= thr) return c;
+            }
+            return 3;
+        };
+        for (int base = 0; base < m; base += QT) {
+            const int i = base + tid;
+            int c = 3;
+            double d = 0.0;
+            if (i < m && i != e0 && i != e1 && i != e2) c = classify(i, d);
+            for (int k = 0; k < 3; k++) {
+                const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
+                if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
+            }
+            if (c < 3) {
+                if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = i; ft[c] = 0; }
+                else if (d == fd[c]) ft[c] = 1;
+            }
+        }
+        if (doubt) { S.state = 2; S.reason = 3; }
+        // the farthest point of each of the three sets
+        double od[2];
+        int oi[2], ot[2];
+        double far_d[3];
+        int far_i[3], far_t[3];
+        block_far(S, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
+        far_d[0] = od[0]; far_i[0] = oi[0]; far_t[0] = ot[0] | 0;
+        far_d[1] = od[1]; far_i[1] = oi[1]; far_t[1] = ot[1];
+        block_far(S, fd[2], fi[2], 0.0, -1, od, oi, ot);
+        far_d[2] = od[0]; far_i[2] = oi[0]; far_t[2] = ot[0];
+        // private ties (one thread met the same distance twice)
+        for (int c = 0; c < 3; c++)
+            if (ft[c] && fi[c] >= 0 && fd[c] == far_d[c]) { S.state = 2; S.reason = 4; }
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt[3] = {S.c0[0], S.c0[1], S.c0[2]};
+            const int fs[3] = {f0, f1, f2};
+            int at = 0;
+            for (int c = 0; c < 3; c++) {
+                if (far_t[c]) { S.state = 2; S.reason = 4; }
+                S.total[fs[c]] = cnt[c];
+                S.far_idx[fs[c]] = far_i[c];
+                if (cnt[c] > 0) { S.np[fs[c]] = 1; S.plo[fs[c]][0] = at; S.pcnt[fs[c]][0] = cnt[c]; }
+                S.c1[c] = at;                      // where the set's run starts
+                S.c0[c] = 0;
+                at += cnt[c];
+            }
+            // qh_furthestnext: the facet with the farthest outside point goes to the front of the list
+            int bestf = 0;
+            double bestd = -1e300;
+            for (int c = 0; c < 3; c++)
+                if (cnt[c] > 0 && far_d[c] > bestd) { bestd = far_d[c]; bestf = fs[c]; }
+            if (bestf && bestf != S.head) {
+                list_remove(S, bestf);
+                S.prev[bestf] = -1;
+                S.next[bestf] = (short)S.head;
+                S.prev[S.head] = (short)bestf;
+                S.head = bestf;
+            }
+            S.nextf = S.head;
+        }
+        __syncthreads();
+        if (S.state == 2) {
+            if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            return;
+        }
+        int *A = bufs0;
+        for (int base = 0; base < m; base += QT) {
+            const int i = base + tid;
+            int c = 3;
+            double d = 0.0;
+            if (i < m && i != e0 && i != e1 && i != e2) c = classify(i, d);
+            for (int k = 0; k < 3; k++) {
+                const int slot = wave_slot(&S.c0[k], c == k);
+                if (c == k) A[S.c1[k] + slot] = i;
+            }
+        }
+        __syncthreads();
+    }
+    // qh_buildhull
+    for (int step = 0; step < m + 8; step++) {
+        if (tid == 0) {
+            const double minvisible = S.thr[1], band = S.thr[4];
+            while (S.nextf != 0 && S.total[S.nextf] == 0) S.nextf = S.next[S.nextf];           // qh_nextfurthest
+            if (S.nextf == 0)
+                S.state = 1;
+            else {
+                const int facet = S.nextf, apex = S.far_idx[facet];
+                const double ax = x[apex], ay = y[apex];
+                S.apex = apex;
+                // qh_findhorizon: visible facets move to the end of the list as they are found
+                list_remove(S, facet);
+                list_append(S, facet);
+                S.visible[facet] = 1;
+                int nvis = 1;
+                S.vis[0] = facet;
+                for (int k = 0; k < nvis && S.state == 0; k++) {
+                    const int v = S.vis[k];
+                    for (int j = 0; j < 2; j++) {
+                        const int g = j ? S.nb1[v] : S.nb0[v];
+                        if (S.visible[g]) continue;
+                        const double d = plane_dist(S, g, ax, ay);
+                        if (fabs(d) < band) { S.state = 2; S.reason = 5; break; }
+                        if (d > minvisible) {
+                            if (nvis == QV) { S.state = 2; S.reason = 6; break; }
+                            list_remove(S, g);
+                            list_append(S, g);
+                            S.visible[g] = 1;
+                            S.vis[nvis++] = g;
+                        }
+                    }
+                }
+                S.nvis = nvis;
+                // qh_makenew_simplicial: one facet per horizon ridge, the apex first
+                int n_new = 0;
+                for (int k = 0; k < nvis && S.state == 0; k++) {
+                    const int v = S.vis[k];
+                    for (int j = 0; j < 2; j++) {
+                        const int g = j ? S.nb1[v] : S.nb0[v];
+                        if (S.visible[g]) continue;
+                        const int hskip = S.nb0[g] == v ? 0 : 1;
+                        if (n_new == 2 || S.n_free == 0) { S.state = 2; S.reason = n_new == 2 ? 7 : 8; break; }
+                        const int nf = S.free_slot[--S.n_free];
+                        S.v0[nf] = apex;
+                        S.v1[nf] = hskip ? S.v0[g] : S.v1[g];
+                        S.top[nf] = S.top[g] ? (hskip & 1) != 0 : (hskip & 1) == 0;
+                        S.visible[nf] = 0;
+                        S.np[nf] = 0;
+                        S.total[nf] = 0;
+                        S.far_idx[nf] = -1;
+                        S.nb0[nf] = (short)g;
+                        if (hskip) S.nb1[g] = (short)nf; else S.nb0[g] = (short)nf;
+                        set_plane(S, nf, x, y);
+                        list_append(S, nf);
+                        S.newf[n_new++] = nf;
+                    }
+                }
+                if (S.state == 0 && n_new != 2) { S.state = 2; S.reason = 7; }
+                if (S.state == 0) {
+                    S.nb1[S.newf[0]] = (short)S.newf[1];
+                    S.nb1[S.newf[1]] = (short)S.newf[0];
+                    // where Qhull's default merging would look twice
+                    for (int k = 0; k < 2; k++) {
+                        const int a = S.newf[k], g = S.nb0[a], b = S.newf[1 - k];
+                        const int w = S.v0[g] == S.v1[a] ? S.v1[g] : S.v0[g], r = S.v1[b];
+                        if (plane_dist(S, a, x[w], y[w]) > -band || plane_dist(S, g, ax, ay) > -band ||
+                            plane_dist(S, a, x[r], y[r]) > -band) {
+                            S.state = 2;
+                            S.reason = 9;
+                        }
+                    }
+                    for (int k = 0; k < QV * QP; k++) S.c0[k] = S.c1[k] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        if (S.state != 0) break;
+        // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
+        const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
+        const double minoutside = S.thr[2], band = S.thr[4];
+        double fd[2] = {0, 0};
+        int fi[2] = {-1, -1}, ft[2] = {0, 0};
+        bool doubt = false;
+        for (int k = 0; k < nvis; k++) {
+            const int v = S.vis[k], np = S.np[v];
+            for (int q = 0; q < np; q++) {
+                const unsigned word = (unsigned)S.plo[v][q];
+                const int lo = (int)(word & IDX_MASK), from = (int)(word >> 31), cnt = S.pcnt[v][q], slot = k * QP + q;
+                const int *src = from ? bufs1 : bufs0;
+                int *dst = from ? bufs0 : bufs1;
+                for (int base = 0; base < cnt; base += QT) {
+                    const int i = base + tid;
+                    int c = 2, p = -1;
+                    double d = 0.0;
+                    if (i < cnt) {
+                        p = src[lo + i];
+                        if (p != apex) {
+                            const double px = x[p], py = y[p];
+                            d = plane_dist(S, a0, px, py);
+                            if (fabs(d) < band) doubt = true;
+                            if (d >= minoutside) c = 0;
+                            else {
+                                d = plane_dist(S, a1, px, py);
+                                if (fabs(d) < band) doubt = true;
+                                if (d >= minoutside) c = 1;
+                            }
+                        }
+                    }
+                    const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);
+                    if (c == 0) dst[lo + s0] = p;
+                    if (c == 1) dst[lo + cnt - 1 - s1] = p;
+                    if (c < 2) {
+                        if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = p; ft[c] = 0; }
+                        else if (d == fd[c]) ft[c] = 1;
+                    }
+                }
+            }
+        }
+        double od[2];
+        int oi[2], ot[2];
+        block_far(S, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
+        for (int c = 0; c < 2; c++)
+            if (ft[c] && fi[c] >= 0 && fd[c] == od[c]) doubt = true;
+        if (doubt) { S.state = 2; S.reason = 10; }
+        __syncthreads();
+        if (tid == 0 && S.state == 0) {
+            if (ot[0] || ot[1]) { S.state = 2; S.reason = 4; }
+            const int child[2] = {a0, a1};
+            for (int k = 0; k < nvis && S.state == 0; k++) {
+                const int v = S.vis[k], np = S.np[v];
+                for (int q = 0; q < np; q++) {
+                    const unsigned word = (unsigned)S.plo[v][q];
+                    const int lo = (int)(word & IDX_MASK), to = (int)(word >> 31) ^ 1, cnt = S.pcnt[v][q], slot = k * QP + q;
+                    const int c0 = S.c0[slot], c1 = S.c1[slot];
+                    const int at[2] = {lo, lo + cnt - c1}, n[2] = {c0, c1};
+                    for (int c = 0; c < 2; c++) {
+                        if (!n[c]) continue;
+                        const int f = child[c];
+                        if (S.np[f] == QP) { S.state = 2; S.reason = 11; break; }
+                        S.plo[f][S.np[f]] = (int)((unsigned)at[c] | ((unsigned)to << 31));
+                        S.pcnt[f][S.np[f]] = n[c];
+                        S.np[f]++;
+                        S.total[f] += n[c];
+                    }
+                }
+            }
+            S.far_idx[a0] = oi[0];
+            S.far_idx[a1] = oi[1];
+            // qh_deletevisible
+            for (int k = 0; k < nvis; k++) {
+                const int v = S.vis[k];
+                list_remove(S, v);
+                S.visible[v] = 0;
+                S.free_slot[S.n_free++] = (short)v;
+            }
+        }
+        __syncthreads();
+        if (S.state != 0) break;
+    }
+    if (tid == 0) {
+        int64_t out = QHULL_DEFER;
+        if (S.state == 1) {
+            int count = 0;
+            for (int f = S.head; f != 0 && count <= QF; f = S.next[f]) count++;
+            // the strict hull the other kernel found has as many vertices, or something was merged or missed
+            if (count == n_hull[s]) out = S.top[S.head] ? S.v0[S.head] : S.v1[S.head];
+            else S.reason = 12;
+        } else if (S.state == 0)
+            S.reason = 13;
+        if (out == QHULL_DEFER) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
+        start[s] = out;
+    }
+}
+
+}  // namespace
+
+// start[s] (device): the first vertex of Qhull's order, -1 where there is no hull or the slice was not selected,
+// QHULL_DEFER where the host has to decide.  scratch: 2 * total int32 entries.
+int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
+                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
+                    int64_t *start, hipStream_t st)
+{
+    if (n_slices <= 0) return PCFIT_OK;
+    qhull_order_kernel<<<dim3((unsigned)n_slices), dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, scratch,
+                                                                    scratch + total, start);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+}  // namespace pcfit
+
+using namespace pcfit;
+
+PCFIT_API int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_t *offsets,
+                                          const int64_t *n_unique, const int64_t *n_hull, const int64_t *select,
+                                          int64_t n_slices, int64_t total_points, void *scratch, size_t scratch_bytes,
+                                          int64_t *start, void *stream)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31) && total_points >= 0, "qhull_start: sizes out of range");
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(ux && uy && offsets && n_unique && n_hull && start, "qhull_start: null pointer");
+    if (!scratch || scratch_bytes < (size_t)total_points * 8) {
+        set_error("qhull_start: the scratch buffer holds %zu bytes, %zu needed", scratch_bytes, (size_t)total_points * 8);
+        return PCFIT_ERR_WORKSPACE;
+    }
+    return qhull_start_dev(ux, uy, offsets, n_unique, n_hull, select, n_slices, total_points, static_cast<int *>(scratch),
+                           start, as_stream(stream));
+}
+
+// tools and tests: how many slices the kernel handed back since the last reset, by cause (1 flat simplex, 2 simplex
+// orientation, 3 first partition near a threshold, 4 tie for the farthest point, 5 horizon near the threshold,
+// 6 visible facets, 7 new facets, 8 facet slots, 9 nearly collinear facets, 10 partition near a threshold,
+// 11 pieces of a set, 12 vertex count, 13 steps)
+PCFIT_API int pcfit_debug_qhull_reasons(int64_t *out16, int reset)
+{
+    PCFIT_ENTER();
+    PCFIT_HIP(hipDeviceSynchronize());
+    PCFIT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pcfit::g_qhull_reason), 16 * sizeof(int64_t)));
+    if (reset) {
+        int64_t zero[16] = {0};
+        PCFIT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pcfit::g_qhull_reason), zero, sizeof(zero)));
+    }
+    return PCFIT_OK;
+}

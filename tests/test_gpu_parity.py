@@ -172,6 +172,74 @@ def test_hybrid_in_qhulls_order_is_the_reference_without_hints():
         assert rel([res["center_x"], res["center_y"], res["radius"]], g[f"fit{i}"]) < 1e-9
 
 
+def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay():
+    """pcfit_qhull_start_batch_dev (one workgroup per slice) on the 720 recorded slices: where it answers, the
+    vertex is the one scipy listed first (tests/golden/qhull_order.npz); it answers on every slice of the kinds
+    in general position, and hands back only slices the host replay is not sure of either, or sure and right."""
+    import ctypes as C
+    import torch
+    from oracle import qhull2d as Q
+    g = load_golden("qhull_order")
+    kinds = [str(k) for k in g["kinds"]]
+    cases = [(kinds[int(k)], Q.make_case(kinds[int(k)], int(n), int(seed))) for k, n, seed, _ in g["cases"]]
+    x = np.concatenate([c[1][:, 0] for c in cases])
+    y = np.concatenate([c[1][:, 1] for c in cases])
+    off = np.concatenate([[0], np.cumsum([len(c[1]) for c in cases])]).astype(np.int64)
+    S, total = len(cases), int(off[-1])
+    host = F.qhull_order_batch(x, y, off)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    p = lambda a: C.c_void_p(a.data_ptr())
+    dx, dy, doff = t(x), t(y), t(off)
+    dnu = t(np.diff(off))
+    dnh = t(g["count"].astype(np.int64))
+    scratch = torch.empty(total * 8, dtype=torch.uint8, device=dev)
+    start = torch.full((S,), -7, dtype=torch.int64, device=dev)
+    why = np.zeros(16, np.int64)
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(dnh), None, S, total, p(scratch),
+                                                total * 8, p(start), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = start.cpu().numpy()
+    deferred = got == -3
+    assert np.array_equal(got[~deferred], g["first"][~deferred])
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    assert int(why.sum()) == int(deferred.sum())
+    # handed back: flat initial simplexes (the ellipses of 30 x 0.01, arcs and 3-point sets: Qhull then searches all
+    # points, which is the host's), and decisions near a threshold (integer grids, points on a square's edge,
+    # clusters far from the origin); on rings, disks, clouds and the cylinder's slabs the kernel answers itself
+    plain = np.array([c[0] in ("ring", "disk", "gauss", "ringf32", "slab") and len(c[1]) >= 8 for c in cases])
+    assert plain.sum() > 200 and deferred[plain].mean() < 0.01, (deferred[plain].mean(), why.tolist())
+    assert why[1] + why[3] + why[4] + why[5] + why[9] + why[10] == deferred.sum(), why.tolist()
+    # the library's own route (device first, host for what it hands back) equals the host replay everywhere
+    h = F.unique_hull_batch(x, y, off, hull_start="qhull")
+    for s_ in range(S):
+        nh = int(h["n_hull"][s_])
+        if nh >= 3 and host["start"][s_] >= 0:
+            assert h["hull_idx"][off[s_]] == host["start"][s_], (s_, cases[s_][0])
+    # the slab slices of the hybrid fixtures, long ones included
+    for name, count in (("hull_hybrid", 10), ("long_slices", 3)):
+        gg = load_golden(name)
+        for i in range(count):
+            if name == "hull_hybrid":
+                uniq = gg[f"uniq{i}"]
+            else:
+                n, seed, outlier, dup = gg["cases"][i]
+                pts = R.make_slab(int(n), int(seed), float(outlier), int(dup))
+                uniq = R.unique_rows(pts[(pts[:, 2] >= -0.5) & (pts[:, 2] <= 0.5), :2])
+            q = gg[f"qhull{i}"]
+            if len(q) < 3:
+                continue
+            m = len(uniq)
+            st1 = torch.full((1,), -7, dtype=torch.int64, device=dev)
+            sc = torch.empty(m * 8, dtype=torch.uint8, device=dev)
+            keep = [t(uniq[:, 0]), t(uniq[:, 1]), t(np.array([0, m])), t(np.array([m])), t(np.array([len(q)]))]
+            F.check(F.lib().pcfit_qhull_start_batch_dev(*[p(a) for a in keep], None, 1, m, p(sc), m * 8, p(st1), None))
+            torch.cuda.synchronize()
+            F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+            assert int(st1.item()) == int(q[0]), (name, i, int(st1.item()), why.tolist())
+
+
 def _ring50k():
     gen = np.random.default_rng(64)
     th = gen.uniform(0, 2 * np.pi, 50000)
