@@ -33,6 +33,7 @@ struct Shared {
     double red_d[QT / 64];
     int red_i[QT / 64];
     double thr[6];               // distround, minvisible, minoutside, distoutside, band, (unused)
+    double search[3];            // the simplex search: best determinant so far, the one that ends it, near zero
     int ext[4];
 };
 
@@ -202,9 +203,63 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
                 if (det > bestdet) { bestdet = det; third = i; }
             }
         const double target = (x[maxx] - x[minx]) * maxwidth, nearzero = 10 * (80 * sumabs * eps);
-        if (minx == maxx || third < 0 || bestdet < nearzero || bestdet / target < 1e-3)
-            { S.state = 2; S.reason = 1; }          // a flat simplex: Qhull's search of all points is the host's
-        else {
+        S.ext[0] = minx; S.ext[1] = maxx; S.ext[2] = third;
+        S.search[0] = bestdet; S.search[1] = 10 * 1e-3 * target; S.search[2] = nearzero;
+        S.nvis = 0;
+        if (minx == maxx)
+            { S.state = 2; S.reason = 1; }          // all points on one vertical line: no hull
+        else if (third < 0 || bestdet < nearzero || bestdet / target < 1e-3)
+            S.nvis = 1;                             // a flat simplex: Qhull looks through all other points
+        S.vis[0] = xlo; S.vis[1] = xhi; S.vis[2] = ylo; S.vis[3] = yhi;
+    }
+    __syncthreads();
+    if (S.state == 2) {
+        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        return;
+    }
+    if (S.nvis == 1) {
+        // qh_maxsimplex's search, in the points' order: it stops at the first point that spans a hundredth of what
+        // the extents allow (and is not near zero); if none does, the largest determinant wins, the first of equals
+        const int minx = S.ext[0], maxx = S.ext[1];
+        const double mindet = S.search[1], nearzero = S.search[2];
+        const double ax = x[minx], ay = y[minx], bx = x[maxx], by = y[maxx];
+        int first = 0x7fffffff, at = -1;
+        double best = -1.0;
+        for (int i = tid; i < m; i += QT) {
+            if (i == xlo || i == xhi || i == ylo || i == yhi) continue;
+            const double det = fabs((ax - x[i]) * (by - y[i]) - (bx - x[i]) * (ay - y[i]));
+            if (det > mindet && !(det < nearzero) && i < first) first = i;
+            if (det > best) { best = det; at = i; }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            first = min(first, __shfl_xor(first, d));
+            const double ob = __shfl_xor(best, d);
+            const int oa = __shfl_xor(at, d);
+            if (oa >= 0 && (at < 0 || ob > best || (ob == best && oa < at))) { best = ob; at = oa; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { S.red_d[tid >> 6] = best; S.red_i[tid >> 6] = at; S.c0[tid >> 6] = first; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < QT / 64; w++) {
+                first = min(first, S.c0[w]);
+                const double ob = S.red_d[w];
+                const int oa = S.red_i[w];
+                if (oa >= 0 && (at < 0 || ob > best || (ob == best && oa < at))) { best = ob; at = oa; }
+            }
+            if (first != 0x7fffffff) S.ext[2] = first;
+            else if (at >= 0 && best > S.search[0]) { S.ext[2] = at; S.search[0] = best; }
+            if (first == 0x7fffffff && (S.ext[2] < 0 || !(S.search[0] > 0.0))) { S.state = 2; S.reason = 1; }
+        }
+        __syncthreads();
+        if (S.state == 2) {
+            if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            return;
+        }
+    }
+    if (tid == 0) {
+        {
+            const int minx = S.ext[0], maxx = S.ext[1], third = S.ext[2];
             // qh_createsimplex, qh_initialhull
             for (int k = 0; k < QF; k++) S.free_slot[k] = (short)(QF - 1 - k);      // slots QF-1 .. 1 (0 is the tail)
             S.n_free = QF - 1;

@@ -1,0 +1,58 @@
+"""Randomised comparison of the device replay of Qhull's construction (through pcfit_unique_hull_batch with
+hull_start = PCFIT_HULL_START_QHULL: device kernel first, host replay for what it hands back) with the host
+replay alone (pcfit_qhull_order_batch, itself checked against scipy by tests/sweep_qhull_order.py).  Needs a GPU.
+Not collected by pytest:  python tests/sweep_qhull_device.py [rounds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # noqa: F401  (first, so that both use the HIP runtime torch ships)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.qhull2d import KINDS, make_case     # noqa: E402  (inputs only)
+from pointcloud_amd import _ffi as F            # noqa: E402
+
+
+def main(rounds=20, seed=0):
+    gen = np.random.default_rng(seed)
+    bad = slices = points = handed = 0
+    why_all = np.zeros(16, np.int64)
+    t0 = time.time()
+    for r in range(rounds):
+        xs, ys, off = [], [], [0]
+        for k in range(int(gen.integers(50, 600))):
+            xy = make_case(KINDS[int(gen.integers(len(KINDS)))],
+                           int(gen.choice([3, 4, 6, 10, 30, 200, 1500, 8192, 9000, 30000, 70000])), int(gen.integers(1 << 30)))
+            if gen.random() < 0.2:                       # duplicates and another order: the library sorts and dedups
+                xy = np.concatenate([xy, xy[gen.integers(0, len(xy), len(xy) // 3 + 1)]])
+            xy = xy[gen.permutation(len(xy))]
+            xs.append(xy[:, 0]), ys.append(xy[:, 1]), off.append(off[-1] + len(xy))
+        x, y, off = np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64)
+        why = np.zeros(16, np.int64)
+        F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+        h = F.unique_hull_batch(x, y, off, hull_start="qhull")
+        F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+        why_all += why
+        host = F.qhull_order_batch(h["ux"], h["uy"], off, n_unique=h["n_unique"])
+        for s in range(len(off) - 1):
+            nh = int(h["n_hull"][s])
+            if nh < 3 or host["start"][s] < 0:
+                continue
+            walk = h["hull_idx"][off[s]:off[s] + nh]
+            hw = host["walk"][off[s]:off[s] + host["n_walk"][s]]
+            same = walk[0] == host["start"][s] and (not host["sure"][s] or np.array_equal(walk, hw))
+            if not same:
+                bad += 1
+                print("round", r, "slice", s, "points", off[s + 1] - off[s], "device route", walk[:4], "host", hw[:4],
+                      "sure", bool(host["sure"][s]))
+        slices += len(off) - 1
+        points += int(off[-1])
+        handed += int(why.sum())
+    print(f"{rounds} rounds, {slices} slices, {points} points, {time.time() - t0:.0f} s: {bad} differences; "
+          f"handed back to the host {handed} ({why_all.tolist()})")
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)
