@@ -7,7 +7,9 @@ manage device memory themselves (bench.py does, through torch).
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -321,6 +323,24 @@ def get_hull_order():
     return ("canonical", "qhull")[int(v[0])]
 
 
+_order_lock = threading.RLock()
+
+
+@contextlib.contextmanager
+def hull_order(order):
+    """The library's process-wide hull order for the calls made inside the block (None: leave it as it is)."""
+    if order is None:
+        yield
+        return
+    with _order_lock:
+        before = get_hull_order()
+        set_hull_order(order)
+        try:
+            yield
+        finally:
+            set_hull_order(before)
+
+
 def unique_hull_batch(x, y, offsets=None, hull_start=None):
     x, y, offsets = as_csr(x, y, offsets)
     S = offsets.size - 1
@@ -471,10 +491,10 @@ def host_window_counts(points, z_lo, z_hi, n_threads: int = 0):
 
 
 def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
-                      huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None):
+                      huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None, order=None):
     """bin_slices + hybrid_batch without the round trip of the binned points: the scan (an (N,3) array, uploaded
     for this call, or a DeviceScan already on the GPU) is binned on the device and only per-slice results and
-    candidates come back.  With hull candidates the candidate arrays start small and the call is repeated once
+    candidates come back.  ``order``: "qhull" / "canonical" for this call (None: the process-wide setting).  With hull candidates the candidate arrays start small and the call is repeated once
     with the needed size if they were too small."""
     if isinstance(points, DeviceScan):
         if not points._handle:
@@ -507,9 +527,10 @@ def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_i
         amm = np.zeros((S, 2), np.int64)
         ov = np.zeros((S, 5))
         dev = np.full((S, K), np.nan) if want_profile else None
-        rc = head[0](*head[1], _p(z_lo), _p(z_hi), S, inlier_tol, max_trials, min_inliers_frac, _p(rr), huber_delta,
-                     1 if use_hull else 0, int(seed), _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off),
-                     _p(cx_), _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
+        with hull_order(order):
+            rc = head[0](*head[1], _p(z_lo), _p(z_hi), S, inlier_tol, max_trials, min_inliers_frac, _p(rr), huber_delta,
+                         1 if use_hull else 0, int(seed), _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off),
+                         _p(cx_), _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
         if rc != 0 and int(cand_off[-1]) > cap:           # candidate arrays too small: the count is known now
             cand_capacity = int(cand_off[-1])
             continue

@@ -31,6 +31,11 @@ class Config:
     overlay_all: bool = True
     z_min: Optional[float] = None
     z_max: Optional[float] = None
+    # not in the reference: "qhull" lists every slice's hull vertices from the vertex scipy's ConvexHull starts
+    # with (analyzer.py:67 -> circle_fitting.py:189-192), so candidates, sampled triples and fits are the
+    # reference's own; "canonical" starts at the lexicographically smallest vertex (no replay of Qhull, and
+    # slices longer than 1024 points drop their interior points before they are sorted: faster)
+    hull_order: str = "qhull"
 
 
 # fit parameters the reference hard-codes in process_slice (analyzer.py:67-71)
@@ -98,13 +103,16 @@ class CylinderAnalyzer:
     # ------------------------------------------------------------------ reference API
     def process_slice(self, points: np.ndarray, z_center: float, *, hull_start=None
                       ) -> Tuple[dict, "pd.DataFrame", str]:  # noqa: F821
-        """Process a single slice of points (reference: analyzer.py:46-129).  ``hull_start``: None, an index
-        or "qhull", as in utils.circle_fitting.fit_circle_hybrid_at_z."""
+        """Process a single slice of points (reference: analyzer.py:46-129).  ``hull_start``: an index, "qhull"
+        or "canonical", as in utils.circle_fitting.fit_circle_hybrid_at_z; None: what the configuration says."""
         import pandas as pd
 
         if not isinstance(points, _ffi.DeviceScan):
             points = np.asarray(points, float)
-        hs = hull_start if hull_start is None or isinstance(hull_start, str) else np.array([hull_start], np.int64)
+        if hull_start is None:
+            hull_start = self.config.hull_order
+        hs = (np.array([-1], np.int64) if hull_start == "canonical" else hull_start if isinstance(hull_start, str)
+              else np.array([hull_start], np.int64))
         dz = self.config.z_step / 2.0
         offsets, x, y, _ = _ffi.bin_slices(points, np.array([z_center - dz]), np.array([z_center + dz]),
                                            want_perm=False)
@@ -155,7 +163,8 @@ class CylinderAnalyzer:
         z_centers = np.asarray(z_centers, float)
         # the scan is uploaded once and binned on the device; only per-window results come back
         h = _ffi.scan_hybrid_batch(points, z_centers - dz, z_centers + dz, _FIT["inlier_tol"], _FIT["max_trials"],
-                                   _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"])
+                                   _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"],
+                                   order=self.config.hull_order)
         # Building hundreds of thousands of small lists and dicts makes the cyclic garbage collector walk them
         # again and again (a 4x slowdown measured on the candidate lists alone); it is paused while the
         # results are put together, and they are handed out afterwards.

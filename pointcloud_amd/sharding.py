@@ -199,11 +199,11 @@ def analyze_sharded(analyzer, points, group=None, progress_callback=None):
         args = (_FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None, _FIT["huber_delta"],
                 _FIT["use_hull"])
         if resident:
-            h = _ffi.scan_hybrid_batch(points, lo, hi, *args)
+            h = _ffi.scan_hybrid_batch(points, lo, hi, *args, order=analyzer.config.hull_order)
         else:
             with DeviceScan(points, z_range=(lo[0], hi[-1])) as part:
                 if len(part):
-                    h = _ffi.scan_hybrid_batch(part, lo, hi, *args)
+                    h = _ffi.scan_hybrid_batch(part, lo, hi, *args, order=analyzer.config.hull_order)
                 else:
                     h = dict(empty, offsets=np.zeros(s1 - s0 + 1, np.int64), status=np.ones(s1 - s0, np.int32),
                              cand_offsets=np.zeros(s1 - s0 + 1, np.int64), argmax=np.zeros(s1 - s0, np.int64),

@@ -86,17 +86,17 @@ def fit_circle_hybrid_at_z(
     huber_delta: float = 1.0,
     use_hull_vertices_only: bool = True,
     *,
-    hull_start=None,
+    hull_start="qhull",
 ) -> Optional[Dict[str, np.ndarray]]:
     """Reference: utils/circle_fitting.py:146-232.
 
     ``hull_start`` (not in the reference): where the candidate walk around the
-    hull begins.  None: at the lexicographically smallest vertex (or where
-    ``pointcloud_amd.set_hull_order`` says); an int: at that vertex, an index
-    into the sorted distinct slice points; "qhull": where
-    ``scipy.spatial.ConvexHull(xy).vertices`` begins (circle_fitting.py:189-190),
-    found by replaying Qhull's construction on the host - the candidates, the
-    sampled triples and with them the fit are then the reference's own.
+    hull begins.  "qhull" (default): where ``scipy.spatial.ConvexHull(xy).vertices``
+    begins (circle_fitting.py:189-190), found by replaying Qhull's construction -
+    the candidates, the sampled triples and with them the fit are then the
+    reference's own.  "canonical": at the lexicographically smallest vertex (no
+    replay).  An int: at that vertex, an index into the sorted distinct slice
+    points.  None: where ``pointcloud_amd.set_hull_order`` says.
     """
     points_xyz = np.asarray(points_xyz)
     if points_xyz.ndim != 2 or points_xyz.shape[1] != 3:
@@ -106,7 +106,10 @@ def fit_circle_hybrid_at_z(
     offsets, x, y, _ = _ffi.bin_slices(points_xyz, lo, hi, want_perm=False)
     if offsets[1] < 3:
         return None
-    hs = hull_start if hull_start is None or isinstance(hull_start, str) else np.array([hull_start], np.int64)
+    if hull_start == "canonical":
+        hs = np.array([-1], np.int64)
+    else:
+        hs = hull_start if hull_start is None or isinstance(hull_start, str) else np.array([hull_start], np.int64)
     h = _ffi.hybrid_batch(x, y, offsets, inlier_tol, max_trials, min_inliers_frac, r_range, huber_delta,
                           use_hull_vertices_only, hs, want_profile=False)
     if h["status"][0] != 0:

@@ -83,7 +83,7 @@ REFERENCE_SIGNATURES = {
                                      "rng_seed=42)",
     "circle_fitting.fit_circle_hybrid_at_z": "(points_xyz, z_elevation, z_tolerance, inlier_tol=0.5, max_trials=4000, "
                                              "min_inliers_frac=0.1, r_range=None, huber_delta=1.0, "
-                                             "use_hull_vertices_only=True, *, hull_start=None)",
+                                             "use_hull_vertices_only=True, *, hull_start='qhull')",
     "boundary.boundary_by_angle_max": "(points_xy, center=None, bins=720)",
     "boundary.boundary_by_convex_hull": "(points_xy)",
     "boundary.ovality_and_fourier": "(x, y, center_x, center_y, radius)",
@@ -107,7 +107,8 @@ def test_dropin_signatures_match_the_reference():
     assert fields == [("z_step", 2.0), ("max_points_for_speed", 1_000_000), ("min_points_per_slice", 1000),
                       ("inlier_quantile", 0.80), ("boundary_method", "angle_max"), ("angle_bins", 720),
                       ("draw_per_slice_images", True), ("slice_plot_sample_points", 30000), ("overlay_all", True),
-                      ("z_min", None), ("z_max", None)]                       # reference: analyzer.py:17-30
+                      ("z_min", None), ("z_max", None),                       # reference: analyzer.py:17-30
+                      ("hull_order", "qhull")]                                # one field more: Qhull's vertex order
     for meth in ("process_slice", "analyze_file", "analyze_with_progress", "calculate_z_centers"):
         assert callable(getattr(CylinderAnalyzer, meth))
     az = CylinderAnalyzer()

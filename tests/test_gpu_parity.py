@@ -520,17 +520,21 @@ def test_two_runs_are_bitwise_identical():
 
 
 def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
-    """set_hull_order("qhull"): the analyzer's candidates are the reference's `xy[hull.vertices]` in the
-    reference's order, so every slice - the three whose hull holds outliers included - has the reference's
-    boundary points, fit and metrics (tests/golden/analyzer.npz, recorded from the reference itself)."""
+    """The analyzer as it comes (Config.hull_order = "qhull"): its candidates are the reference's
+    `xy[hull.vertices]` in the reference's order, so every slice - the three whose hull holds outliers included -
+    has the reference's boundary points, fit and metrics (tests/golden/analyzer.npz, recorded from the reference
+    itself); the process-wide switch with a configuration that leaves the order open does the same."""
     import pointcloud_amd as P
     g = load_golden("analyzer")
     pts = analyzer_points()
+    res = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000)).analyze_with_progress(pts)
     P.set_hull_order("qhull")
     try:
-        res = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000)).analyze_with_progress(pts)
+        az = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000, hull_order=None))
+        assert az.analyze_with_progress(pts) == res
     finally:
         P.set_hull_order("canonical")
+    assert P.get_hull_order() == "canonical"
     assert len(res) == int(g["n_results"])
     mine = np.array([[r[k] for k in SCALARS] for r in res], dtype=float)
     ref = g["scalars"]
@@ -567,7 +571,8 @@ def test_analyzer_matches_reference_run():
     g = load_golden("analyzer")
     pts = analyzer_points()
     assert hashlib.sha256(pts.tobytes()).hexdigest() == str(g["pts_sha"])
-    az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=1000))
+    assert Config().hull_order == "qhull"
+    az = CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=1000, hull_order="canonical"))
     assert np.array_equal(az.calculate_z_centers(pts), g["z_centers"])
     prog = []
     res = az.analyze_with_progress(pts, progress_callback=prog.append)
@@ -1228,7 +1233,7 @@ def test_one_million_point_scan_through_the_analyzer():
     zc = az.calculate_z_centers(pts)
     assert np.array_equal([r["z_center"] for r in res], zc)
     for s in (0, 57, 123, 198, 199):
-        want, _, warn = R.process_slice(pts, zc[s])
+        want, _, warn = R.process_slice(pts, zc[s], hull_start="qhull")        # hulls walked as scipy's ConvexHull does
         assert warn is None
         got = res[s]
         assert got["n_points_slice"] == want["n_points_slice"] and got["n_edge"] == want["n_edge"]
