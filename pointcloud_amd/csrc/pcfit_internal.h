@@ -20,21 +20,24 @@ int unique_hull_dev(const double *x, const double *y, const int64_t *offsets, in
                     double *ux, double *uy, int64_t *n_unique, int64_t *hull_idx, int64_t *n_hull, int32_t *status,
                     const int64_t *hull_start, void *workspace, size_t workspace_bytes, void *stream, int hull_only);
 size_t unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices, int hull_only);
-// qhull_order.hip: the vertex Qhull's facet list starts with, per slice of distinct points (host cores; only
+// qhull_order.hip: the vertex Qhull's facet list starts with, per slice of sorted distinct points (host cores; only
 // where select is null or select[s] == PCFIT_HULL_START_QHULL, -1 elsewhere), and the turn of device walks
-// to given vertices (tmp: as many entries as hull_idx)
+// to the vertices with given coordinates (where found[s] >= 0; tmp: as many entries as hull_idx)
 int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk);
 int hull_order_mode();         // pcfit_set_hull_order's value
-// qhull_dev.hip: the same replay on the device, one workgroup per slice; start[s] = QHULL_START_DEFER where the
-// host has to decide (anything but the plain course of the construction).  scratch: 2 * total int32 entries.
+int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const double *ux, const double *uy,
+                    const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
+                    hipStream_t st);
+// qhull_dev.hip: the same replay on the device, one workgroup per slice, of slices that are sorted and distinct
+// (n_unique points each) or as they come (n_unique null); start[s] = QHULL_START_DEFER where the host has to
+// decide (anything but the plain course of the construction); start_xy (nullable): the vertex's coordinates.
+// scratch: 2 * total int32 entries.
 constexpr int64_t QHULL_START_DEFER = -3;
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                     const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
-                    int64_t *start, hipStream_t st);
-int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const int64_t *start, int64_t n_slices,
-                    int64_t *hull_idx, int64_t *tmp, hipStream_t st);
+                    int64_t *start, double *start_xy, hipStream_t st);
 
 // longsort.hip: lexicographic sort of (a, b) pairs inside every slice longer than min_len, and the distinct
 // pairs of the sorted slices (see there)

@@ -541,57 +541,88 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
 }
 
 // hull_start entries of PCFIT_HULL_START_QHULL: the walks of those slices are turned to the vertex that Qhull's
-// construction leaves first.  The construction is replayed on the device (qhull_dev.hip); the slices that
-// kernel hands back - decisions inside Qhull's roundoff bands, ties, capacities - have their distinct points
-// brought to the host and are replayed there (all selected slices with PCFIT_QHULL_ON_HOST=1 in the environment).
+// construction leaves first.  The construction is replayed on the device (qhull_dev.hip) from the points in
+// (px, py): the slices' sorted distinct points (counts in n_pts / d_n_pts), or the slices as they are
+// (d_n_pts null, n_pts = their lengths; the walks in dhi then index what the interior filter kept, in dux /
+// duy, and the vertex is found there by its coordinates).  Slices the kernel hands back - decisions inside
+// Qhull's roundoff bands, ties, capacities - have their points brought to the host and are replayed there (all
+// selected slices with PCFIT_QHULL_ON_HOST=1 in the environment).
 static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
-                              const int64_t *n_unique, const int64_t *d_n_unique, int64_t S, int64_t total,
-                              const double *dux, const double *duy, const int64_t *doff, const int64_t *dnh,
-                              int64_t *dhi, hipStream_t st)
+                              const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total, const double *px,
+                              const double *py, const double *dux, const double *duy, const int64_t *doff,
+                              const int64_t *dnh, int64_t *dhi, hipStream_t st)
 {
     bool any = false;
     for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
     if (!any || total <= 0) return PCFIT_OK;
     const char *env = std::getenv("PCFIT_QHULL_ON_HOST");
-    const bool on_host = env && env[0] == '1';
+    const bool on_host = env && env[0] == '1', raw = d_n_pts == nullptr;
     std::vector<int64_t> start((size_t)S, -1);
-    DevBuf dstart, dscratch, dtmp;
+    std::vector<double> start_xy((size_t)S * 2, 0.0);
+    DevBuf dstart, dxy, dscratch, dtmp;
     PCFIT_TRY(dstart.alloc((size_t)S * 8));
+    PCFIT_TRY(dxy.alloc((size_t)S * 16));
     if (!on_host) {
         PCFIT_TRY(dscratch.alloc((size_t)total * 8));
-        PCFIT_TRY(qhull_start_dev(dux, duy, doff, d_n_unique, dnh, d_hull_start, S, total, dscratch.as<int>(),
-                                  dstart.as<int64_t>(), st));
+        PCFIT_TRY(qhull_start_dev(px, py, doff, d_n_pts, dnh, d_hull_start, S, total, dscratch.as<int>(),
+                                  dstart.as<int64_t>(), dxy.as<double>(), st));
         PCFIT_TRY(dstart.download(start.data(), (size_t)S * 8, st));
         PCFIT_HIP(hipStreamSynchronize(st));
     } else {
         for (int64_t s = 0; s < S; s++)
             if (hull_start[s] == PCFIT_HULL_START_QHULL) start[s] = QHULL_START_DEFER;
     }
-    // what the device handed back: those slices' points, packed, to the host replay
+    // what the device handed back: those slices' points, packed (sorted and made distinct here if they are not),
+    // to the host replay
     std::vector<int64_t> which, coff(1, 0);
     for (int64_t s = 0; s < S; s++)
         if (start[s] == QHULL_START_DEFER) {
             start[s] = -1;
-            if (n_unique[s] < 3) continue;
+            if (n_pts[s] < 3) continue;
             which.push_back(s);
-            coff.push_back(coff.back() + n_unique[s]);
+            coff.push_back(coff.back() + n_pts[s]);
         }
     if (!which.empty()) {
+        PCFIT_TRY(dxy.download(start_xy.data(), (size_t)S * 16, st));
         std::vector<double> hx((size_t)coff.back()), hy((size_t)coff.back());
         for (size_t k = 0; k < which.size(); k++) {
             const int64_t s = which[k];
-            PCFIT_HIP(hipMemcpyAsync(hx.data() + coff[k], dux + offsets[s], (size_t)n_unique[s] * 8, hipMemcpyDeviceToHost, st));
-            PCFIT_HIP(hipMemcpyAsync(hy.data() + coff[k], duy + offsets[s], (size_t)n_unique[s] * 8, hipMemcpyDeviceToHost, st));
+            PCFIT_HIP(hipMemcpyAsync(hx.data() + coff[k], px + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
+            PCFIT_HIP(hipMemcpyAsync(hy.data() + coff[k], py + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
         }
         PCFIT_HIP(hipStreamSynchronize(st));
+        std::vector<int64_t> counts(which.size());
+        for (size_t k = 0; k < which.size(); k++) {
+            int64_t m = coff[k + 1] - coff[k];
+            if (raw) {
+                std::vector<std::pair<double, double>> pts((size_t)m);
+                for (int64_t i = 0; i < m; i++) pts[(size_t)i] = {hx[coff[k] + i], hy[coff[k] + i]};
+                std::sort(pts.begin(), pts.end());
+                pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+                m = (int64_t)pts.size();
+                for (int64_t i = 0; i < m; i++) { hx[coff[k] + i] = pts[(size_t)i].first; hy[coff[k] + i] = pts[(size_t)i].second; }
+            }
+            counts[k] = m;
+        }
         std::vector<int64_t> cstart(which.size(), -1);
-        PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), coff.data(), nullptr, (int64_t)which.size(), 0, nullptr,
+        PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), coff.data(), counts.data(), (int64_t)which.size(), 0, nullptr,
                                    cstart.data(), nullptr, nullptr, nullptr));
-        for (size_t k = 0; k < which.size(); k++) start[which[k]] = cstart[k];
+        for (size_t k = 0; k < which.size(); k++) {
+            const int64_t s = which[k];
+            start[s] = cstart[k];
+            if (cstart[k] >= 0) {
+                start_xy[2 * s] = hx[coff[k] + cstart[k]];
+                start_xy[2 * s + 1] = hy[coff[k] + cstart[k]];
+            }
+        }
+        // only the handed-back slices' entries changed: they go back one by one
+        for (size_t k = 0; k < which.size(); k++)
+            PCFIT_HIP(hipMemcpyAsync(dxy.as<double>() + 2 * which[k], start_xy.data() + 2 * which[k], 16,
+                                     hipMemcpyHostToDevice, st));
     }
     PCFIT_TRY(dstart.upload(start.data(), (size_t)S * 8, st));
     PCFIT_TRY(dtmp.alloc((size_t)total * 8));
-    PCFIT_TRY(hull_rotate_dev(doff, dnh, dstart.as<int64_t>(), S, dhi, dtmp.as<int64_t>(), st));
+    PCFIT_TRY(hull_rotate_dev(doff, dnh, dux, duy, dstart.as<int64_t>(), dxy.as<double>(), S, dhi, dtmp.as<int64_t>(), st));
     PCFIT_HIP(hipStreamSynchronize(st));               // start (pageable) and the buffers end with this call
     return PCFIT_OK;
 }
@@ -627,8 +658,8 @@ PCFIT_API int pcfit_unique_hull_batch(const double *x, const double *y, const in
     PCFIT_TRY(dnu.download(n_unique, n_slices * 8, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu.as<int64_t>(), n_slices, total,
-                                 dux.as<double>(), duy.as<double>(), doff.as<int64_t>(), dnh.as<int64_t>(),
-                                 dhi.as<int64_t>(), st));
+                                 dux.as<double>(), duy.as<double>(), dux.as<double>(), duy.as<double>(),
+                                 doff.as<int64_t>(), dnh.as<int64_t>(), dhi.as<int64_t>(), st));
     PCFIT_TRY(dux.download(ux, total * 8, st));
     PCFIT_TRY(duy.download(uy, total * 8, st));
     PCFIT_TRY(dhi.download(hull_idx, total * 8, st));
@@ -760,10 +791,15 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     std::vector<char> hbuf;
 
     // 1. distinct points, rank check, hull
+    // Qhull's order for every slice and nobody asks for the distinct points: the hull comes by the short route
+    // below (interior points of long slices dropped before the sort) and the replay of Qhull's construction
+    // reads the slices as they are
     std::vector<int64_t> qhull_everywhere;
+    bool qhull_raw = false;
     if (!hull_start && use_hull && hull_order_mode() == 1) {
         qhull_everywhere.assign((size_t)S, PCFIT_HULL_START_QHULL);
-        hull_start = qhull_everywhere.data();
+        if (!ux && !uy) qhull_raw = true;
+        else hull_start = qhull_everywhere.data();
     }
     DevBuf dux, duy, dhi, dhs, dws, d1;
     PCFIT_TRY(dux.alloc(total * 8));
@@ -787,9 +823,15 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     memcpy(n_unique, hbuf.data() + nu_at, (size_t)S * 8);
     memcpy(n_hull.data(), hbuf.data() + nh_at, (size_t)S * 8);
     memcpy(status, hbuf.data() + st1_at, (size_t)S * 4);
-    if (use_hull)
+    if (use_hull && qhull_raw) {
+        std::vector<int64_t> lens((size_t)S);
+        for (int64_t s = 0; s < S; s++) lens[(size_t)s] = offsets[s + 1] - offsets[s];
+        PCFIT_TRY(apply_qhull_starts(qhull_everywhere.data(), nullptr, offsets, lens.data(), nullptr, S, total, dxp, dyp,
+                                     dux.as<double>(), duy.as<double>(), doffp, dnh, dhi.as<int64_t>(), st));
+    } else if (use_hull)
         PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu, S, total, dux.as<double>(),
-                                     duy.as<double>(), doffp, dnh, dhi.as<int64_t>(), st));
+                                     duy.as<double>(), dux.as<double>(), duy.as<double>(), doffp, dnh,
+                                     dhi.as<int64_t>(), st));
 
     // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
     int64_t max_cand = 0;

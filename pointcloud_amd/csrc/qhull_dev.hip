@@ -67,38 +67,48 @@ __device__ inline void list_append(Shared &S, int k)
     S.prev[0] = (short)k;
 }
 
-// first index of the least / greatest value over the workgroup (every thread gets the result)
+// Is point a before point b in the lexicographic order of (x, y)?  For sorted distinct input that is a < b; for a
+// slice as it comes (any order, duplicates) it names the point the sorted distinct array would list first.
+__device__ inline bool lex_before(const double *x, const double *y, int a, int b)
+{
+    return x[a] < x[b] || (x[a] == x[b] && y[a] < y[b]);
+}
+__device__ inline bool same_point(const double *x, const double *y, int a, int b) { return x[a] == x[b] && y[a] == y[b]; }
+
+// the point of least / greatest value of coordinate c, the lexicographically first among equals (every thread
+// gets the result)
 template <bool GREATEST>
-__device__ int block_arg_extreme(Shared &S, const double *c, int m)
+__device__ int block_arg_extreme(Shared &S, const double *c, const double *x, const double *y, int m)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double best = 0.0;
     int at = -1;
+    auto better = [&](double ob, int oa, double b, int a) {
+        return oa >= 0 && (a < 0 || (GREATEST ? ob > b : ob < b) || (ob == b && lex_before(x, y, oa, a)));
+    };
     for (int i = tid; i < m; i += QT) {
         const double v = c[i];
-        if (at < 0 || (GREATEST ? v > best : v < best)) { best = v; at = i; }
+        if (better(v, i, best, at)) { best = v; at = i; }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         const double ob = __shfl_xor(best, d);
         const int oa = __shfl_xor(at, d);
-        if (oa >= 0 && (at < 0 || (GREATEST ? ob > best : ob < best) || (ob == best && oa < at))) { best = ob; at = oa; }
+        if (better(ob, oa, best, at)) { best = ob; at = oa; }
     }
     __syncthreads();
     if (lane == 0) { S.red_d[wave] = best; S.red_i[wave] = at; }
     __syncthreads();
     best = S.red_d[0];
     at = S.red_i[0];
-    for (int w = 1; w < QT / 64; w++) {
-        const double ob = S.red_d[w];
-        const int oa = S.red_i[w];
-        if (oa >= 0 && (at < 0 || (GREATEST ? ob > best : ob < best) || (ob == best && oa < at))) { best = ob; at = oa; }
-    }
+    for (int w = 1; w < QT / 64; w++)
+        if (better(S.red_d[w], S.red_i[w], best, at)) { best = S.red_d[w]; at = S.red_i[w]; }
     return at;
 }
 
 // The farthest point of each of two classes, over what every thread has seen: (distance, point) per class in
 // far_d / far_i, and whether the greatest distance was met by more than one point.
-__device__ void block_far(Shared &S, double d0, int i0, double d1, int i1, double out_d[2], int out_i[2], int out_tie[2])
+__device__ void block_far(Shared &S, const double *x, const double *y, double d0, int i0, double d1, int i1,
+                          double out_d[2], int out_i[2], int out_tie[2])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double d[2] = {d0, d1};
@@ -109,7 +119,7 @@ __device__ void block_far(Shared &S, double d0, int i0, double d1, int i1, doubl
             const int oi = __shfl_xor(at[c], s), ot = __shfl_xor(tie[c], s);
             if (oi >= 0) {
                 if (at[c] < 0 || od > d[c]) { d[c] = od; at[c] = oi; tie[c] = ot; }
-                else if (od == d[c] && oi != at[c]) tie[c] = 1;
+                else if (od == d[c] && !same_point(x, y, oi, at[c])) tie[c] = 1;
             }
         }
     }
@@ -126,7 +136,7 @@ __device__ void block_far(Shared &S, double d0, int i0, double d1, int i1, doubl
             const int oi = S.wave_i[c][w], ot = S.wave_tie[c][w];
             if (oi < 0) continue;
             if (out_i[c] < 0 || od > out_d[c]) { out_d[c] = od; out_i[c] = oi; out_tie[c] = ot; }
-            else if (od == out_d[c] && oi != out_i[c]) out_tie[c] = 1;
+            else if (od == out_d[c] && !same_point(x, y, oi, out_i[c])) out_tie[c] = 1;
         }
     }
 }
@@ -144,12 +154,13 @@ __device__ inline int wave_slot(int *counter, bool mine)
     return base + __popcll(votes & ((1ull << lane) - 1ull));
 }
 
-__global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
+__global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
                                                          const int64_t *__restrict__ offsets,
                                                          const int64_t *__restrict__ n_unique,
                                                          const int64_t *__restrict__ n_hull,
                                                          const int64_t *__restrict__ select, int *__restrict__ buf_a,
-                                                         int *__restrict__ buf_b, int64_t *__restrict__ start)
+                                                         int *__restrict__ buf_b, int64_t *__restrict__ start,
+                                                         double *__restrict__ start_xy)
 {
     __shared__ Shared S;
     const int64_t s = blockIdx.x, off = offsets[s];
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         if (tid == 0) start[s] = -1;
         return;
     }
-    const int64_t m64 = n_unique[s];
+    const int64_t m64 = n_unique ? n_unique[s] : offsets[s + 1] - off;
     if (m64 < 3 || n_hull[s] < 3) {
         if (tid == 0) start[s] = -1;
         return;
@@ -172,8 +183,8 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
     int *const bufs0 = buf_a + off, *const bufs1 = buf_b + off;
 
     // qh_maxmin, qh_detroundoff, qh_maxsimplex
-    const int xlo = block_arg_extreme<false>(S, x, m), xhi = block_arg_extreme<true>(S, x, m);
-    const int ylo = block_arg_extreme<false>(S, y, m), yhi = block_arg_extreme<true>(S, y, m);
+    const int xlo = block_arg_extreme<false>(S, x, x, y, m), xhi = block_arg_extreme<true>(S, x, x, y, m);
+    const int ylo = block_arg_extreme<false>(S, y, x, y, m), yhi = block_arg_extreme<true>(S, y, x, y, m);
     if (tid == 0) {
         S.state = 0;
         S.reason = 0;
@@ -195,10 +206,10 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         }
         int third = -1;
         double bestdet = -1.0;
-        if (minx != maxx)
+        if (x[minx] != x[maxx])
             for (int k = 0; k < 4; k++) {
                 const int i = ext[k];
-                if (i == minx || i == maxx) continue;
+                if (same_point(x, y, i, minx) || same_point(x, y, i, maxx)) continue;
                 const double det = fabs((x[minx] - x[i]) * (y[maxx] - y[i]) - (x[maxx] - x[i]) * (y[minx] - y[i]));
                 if (det > bestdet) { bestdet = det; third = i; }
             }
@@ -206,7 +217,7 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         S.ext[0] = minx; S.ext[1] = maxx; S.ext[2] = third;
         S.search[0] = bestdet; S.search[1] = 10 * 1e-3 * target; S.search[2] = nearzero;
         S.nvis = 0;
-        if (minx == maxx)
+        if (x[minx] == x[maxx])
             { S.state = 2; S.reason = 1; }          // all points on one vertical line: no hull
         else if (third < 0 || bestdet < nearzero || bestdet / target < 1e-3)
             S.nvis = 1;                             // a flat simplex: Qhull looks through all other points
@@ -223,33 +234,37 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         const int minx = S.ext[0], maxx = S.ext[1];
         const double mindet = S.search[1], nearzero = S.search[2];
         const double ax = x[minx], ay = y[minx], bx = x[maxx], by = y[maxx];
-        int first = 0x7fffffff, at = -1;
+        int first = -1, at = -1;
         double best = -1.0;
+        auto larger = [&](double ob, int oa, double b, int a) {
+            return oa >= 0 && (a < 0 || ob > b || (ob == b && lex_before(x, y, oa, a)));
+        };
         for (int i = tid; i < m; i += QT) {
-            if (i == xlo || i == xhi || i == ylo || i == yhi) continue;
+            if (same_point(x, y, i, xlo) || same_point(x, y, i, xhi) || same_point(x, y, i, ylo) || same_point(x, y, i, yhi))
+                continue;
             const double det = fabs((ax - x[i]) * (by - y[i]) - (bx - x[i]) * (ay - y[i]));
-            if (det > mindet && !(det < nearzero) && i < first) first = i;
-            if (det > best) { best = det; at = i; }
+            if (det > mindet && !(det < nearzero) && (first < 0 || lex_before(x, y, i, first))) first = i;
+            if (larger(det, i, best, at)) { best = det; at = i; }
         }
         for (int d = 32; d >= 1; d >>= 1) {
-            first = min(first, __shfl_xor(first, d));
+            const int of = __shfl_xor(first, d);
+            if (of >= 0 && (first < 0 || lex_before(x, y, of, first))) first = of;
             const double ob = __shfl_xor(best, d);
             const int oa = __shfl_xor(at, d);
-            if (oa >= 0 && (at < 0 || ob > best || (ob == best && oa < at))) { best = ob; at = oa; }
+            if (larger(ob, oa, best, at)) { best = ob; at = oa; }
         }
         __syncthreads();
         if ((tid & 63) == 0) { S.red_d[tid >> 6] = best; S.red_i[tid >> 6] = at; S.c0[tid >> 6] = first; }
         __syncthreads();
         if (tid == 0) {
             for (int w = 1; w < QT / 64; w++) {
-                first = min(first, S.c0[w]);
-                const double ob = S.red_d[w];
-                const int oa = S.red_i[w];
-                if (oa >= 0 && (at < 0 || ob > best || (ob == best && oa < at))) { best = ob; at = oa; }
+                const int of = S.c0[w];
+                if (of >= 0 && (first < 0 || lex_before(x, y, of, first))) first = of;
+                if (larger(S.red_d[w], S.red_i[w], best, at)) { best = S.red_d[w]; at = S.red_i[w]; }
             }
-            if (first != 0x7fffffff) S.ext[2] = first;
+            if (first >= 0) S.ext[2] = first;
             else if (at >= 0 && best > S.search[0]) { S.ext[2] = at; S.search[0] = best; }
-            if (first == 0x7fffffff && (S.ext[2] < 0 || !(S.search[0] > 0.0))) { S.state = 2; S.reason = 1; }
+            if (first < 0 && (S.ext[2] < 0 || !(S.search[0] > 0.0))) { S.state = 2; S.reason = 1; }
         }
         __syncthreads();
         if (S.state == 2) {
@@ -324,14 +339,14 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
             const int i = base + tid;
             int c = 3;
             double d = 0.0;
-            if (i < m && i != e0 && i != e1 && i != e2) c = classify(i, d);
+            if (i < m && !same_point(x, y, i, e0) && !same_point(x, y, i, e1) && !same_point(x, y, i, e2)) c = classify(i, d);
             for (int k = 0; k < 3; k++) {
                 const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
                 if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
             }
             if (c < 3) {
                 if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = i; ft[c] = 0; }
-                else if (d == fd[c]) ft[c] = 1;
+                else if (d == fd[c] && !same_point(x, y, i, fi[c])) ft[c] = 1;
             }
         }
         if (doubt) { S.state = 2; S.reason = 3; }
@@ -340,10 +355,10 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         int oi[2], ot[2];
         double far_d[3];
         int far_i[3], far_t[3];
-        block_far(S, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
+        block_far(S, x, y, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
         far_d[0] = od[0]; far_i[0] = oi[0]; far_t[0] = ot[0] | 0;
         far_d[1] = od[1]; far_i[1] = oi[1]; far_t[1] = ot[1];
-        block_far(S, fd[2], fi[2], 0.0, -1, od, oi, ot);
+        block_far(S, x, y, fd[2], fi[2], 0.0, -1, od, oi, ot);
         far_d[2] = od[0]; far_i[2] = oi[0]; far_t[2] = ot[0];
         // private ties (one thread met the same distance twice)
         for (int c = 0; c < 3; c++)
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
             const int i = base + tid;
             int c = 3;
             double d = 0.0;
-            if (i < m && i != e0 && i != e1 && i != e2) c = classify(i, d);
+            if (i < m && !same_point(x, y, i, e0) && !same_point(x, y, i, e1) && !same_point(x, y, i, e2)) c = classify(i, d);
             for (int k = 0; k < 3; k++) {
                 const int slot = wave_slot(&S.c0[k], c == k);
                 if (c == k) A[S.c1[k] + slot] = i;
@@ -474,6 +489,7 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
         if (S.state != 0) break;
         // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
+        const double apex_x = x[apex], apex_y = y[apex];
         const double minoutside = S.thr[2], band = S.thr[4];
         double fd[2] = {0, 0};
         int fi[2] = {-1, -1}, ft[2] = {0, 0};
@@ -491,8 +507,8 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
                     double d = 0.0;
                     if (i < cnt) {
                         p = src[lo + i];
-                        if (p != apex) {
-                            const double px = x[p], py = y[p];
+                        const double px = x[p], py = y[p];
+                        if (px != apex_x || py != apex_y) {
                             d = plane_dist(S, a0, px, py);
                             if (fabs(d) < band) doubt = true;
                             if (d >= minoutside) c = 0;
@@ -508,14 +524,14 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
                     if (c == 1) dst[lo + cnt - 1 - s1] = p;
                     if (c < 2) {
                         if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = p; ft[c] = 0; }
-                        else if (d == fd[c]) ft[c] = 1;
+                        else if (d == fd[c] && !same_point(x, y, i, fi[c])) ft[c] = 1;
                     }
                 }
             }
         }
         double od[2];
         int oi[2], ot[2];
-        block_far(S, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
+        block_far(S, x, y, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
         for (int c = 0; c < 2; c++)
             if (ft[c] && fi[c] >= 0 && fd[c] == od[c]) doubt = true;
         if (doubt) { S.state = 2; S.reason = 10; }
@@ -566,20 +582,24 @@ __global__ __launch_bounds__(QT) void qhull_order_kernel(const double *__restric
             S.reason = 13;
         if (out == QHULL_DEFER) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
         start[s] = out;
+        if (start_xy && out >= 0) { start_xy[2 * s] = x[out]; start_xy[2 * s + 1] = y[out]; }
     }
 }
 
 }  // namespace
 
 // start[s] (device): the first vertex of Qhull's order, -1 where there is no hull or the slice was not selected,
-// QHULL_DEFER where the host has to decide.  scratch: 2 * total int32 entries.
+// QHULL_DEFER where the host has to decide; start_xy (nullable): its coordinates.  The points of a slice may
+// come sorted and distinct (n_unique of them) or as they are (n_unique null: the whole slice, any order,
+// duplicates allowed - the answer is the same point, its index then names one of its copies).
+// scratch: 2 * total int32 entries.
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                     const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
-                    int64_t *start, hipStream_t st)
+                    int64_t *start, double *start_xy, hipStream_t st)
 {
     if (n_slices <= 0) return PCFIT_OK;
     qhull_order_kernel<<<dim3((unsigned)n_slices), dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, scratch,
-                                                                    scratch + total, start);
+                                                                    scratch + total, start, start_xy);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -596,13 +616,13 @@ PCFIT_API int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, co
     PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31) && total_points >= 0, "qhull_start: sizes out of range");
     if (n_slices == 0) return PCFIT_OK;
-    PCFIT_REQUIRE(ux && uy && offsets && n_unique && n_hull && start, "qhull_start: null pointer");
+    PCFIT_REQUIRE(ux && uy && offsets && n_hull && start, "qhull_start: null pointer");
     if (!scratch || scratch_bytes < (size_t)total_points * 8) {
         set_error("qhull_start: the scratch buffer holds %zu bytes, %zu needed", scratch_bytes, (size_t)total_points * 8);
         return PCFIT_ERR_WORKSPACE;
     }
     return qhull_start_dev(ux, uy, offsets, n_unique, n_hull, select, n_slices, total_points, static_cast<int *>(scratch),
-                           start, as_stream(stream));
+                           start, nullptr, as_stream(stream));
 }
 
 // tools and tests: how many slices the kernel handed back since the last reset, by cause (1 flat simplex, 2 simplex

@@ -472,23 +472,27 @@ void Replay::walk(int64_t *out, int64_t cap, int64_t *first) const
     }
 }
 
-// a device array of walks turned to start at the named vertex (no change where start[s] < 0 or not a vertex)
+// a device array of walks turned to start at the vertex with the given coordinates (no change where found[s] is
+// not 1 or no vertex has them)
 __global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restrict__ offsets,
                                                           const int64_t *__restrict__ n_hull,
-                                                          const int64_t *__restrict__ start,
+                                                          const double *__restrict__ ux, const double *__restrict__ uy,
+                                                          const int64_t *__restrict__ found,
+                                                          const double *__restrict__ start_xy,
                                                           int64_t *__restrict__ hull_idx, int64_t *__restrict__ tmp)
 {
     __shared__ int found_at;
-    const int64_t s = blockIdx.x, off = offsets[s], h = n_hull[s], want = start[s];
-    if (want < 0 || h <= 0)
+    const int64_t s = blockIdx.x, off = offsets[s], h = n_hull[s];
+    if (found[s] < 0 || h <= 0)
         return;
+    const double sx = start_xy[2 * s], sy = start_xy[2 * s + 1];
     if (threadIdx.x == 0)
         found_at = 0x7fffffff;
     __syncthreads();
     for (int64_t i = threadIdx.x; i < h; i += 256) {
         const int64_t v = hull_idx[off + i];
         tmp[off + i] = v;
-        if (v == want)
+        if (ux[off + v] == sx && uy[off + v] == sy)
             atomicMin(&found_at, (int)i);
     }
     __syncthreads();
@@ -537,11 +541,13 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
     return PCFIT_OK;
 }
 
-int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const int64_t *start, int64_t n_slices,
-                    int64_t *hull_idx, int64_t *tmp, hipStream_t st)
+int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const double *ux, const double *uy,
+                    const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
+                    hipStream_t st)
 {
     if (n_slices <= 0) return PCFIT_OK;
-    hull_rotate_kernel<<<dim3((unsigned)n_slices), dim3(256), 0, st>>>(offsets, n_hull, start, hull_idx, tmp);
+    hull_rotate_kernel<<<dim3((unsigned)n_slices), dim3(256), 0, st>>>(offsets, n_hull, ux, uy, found, start_xy, hull_idx,
+                                                                       tmp);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
