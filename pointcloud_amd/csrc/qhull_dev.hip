@@ -174,8 +174,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         if (tid == 0) start[s] = -1;
         return;
     }
-    if (m64 >= (1ll << 30)) {
-        if (tid == 0) start[s] = QHULL_DEFER;
+    if (m64 >= (1ll << 30) || n_hull[s] > QF - 2) {                // more facets at the end than there are slots
+        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[8], 1ull); }
         return;
     }
     const int m = (int)m64;

@@ -216,6 +216,14 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
         nh = int(h["n_hull"][s_])
         if nh >= 3 and host["start"][s_] >= 0:
             assert h["hull_idx"][off[s_]] == host["start"][s_], (s_, cases[s_][0])
+    # a hull of more vertices than the kernel has facet slots (every point of a circle): the host replay takes it
+    th = np.linspace(0.0, 2 * np.pi, 3000, endpoint=False)
+    circ = np.unique(np.stack([5 * np.cos(th) + 0.25, 5 * np.sin(th) - 1.5], 1), axis=0)
+    hc = F.unique_hull_batch(circ[:, 0].copy(), circ[:, 1].copy(), None, hull_start="qhull")
+    want = F.qhull_order_batch(circ[:, 0].copy(), circ[:, 1].copy(), None)
+    assert int(hc["n_hull"][0]) > 2000 and hc["hull_idx"][0] == want["start"][0]
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    assert why[8] == 1
     # the slab slices of the hybrid fixtures, long ones included
     for name, count in (("hull_hybrid", 10), ("long_slices", 3)):
         gg = load_golden(name)
