@@ -348,7 +348,8 @@ int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_
 /* How many slices that kernel handed back since the last reset, by cause (out16[1..13]: flat simplex, simplex
  * orientation, first partition near a threshold, tie for the farthest point, horizon near the threshold, more
  * than 8 visible facets, new facets, facet slots, nearly collinear facets, partition near a threshold, pieces
- * of an outside set, vertex count, steps).  For tools and tests; synchronises the device. */
+ * of an outside set, vertex count, steps; out16[14], out16[15]: insertions made and points visited after the
+ * first partition).  For tools and tests; synchronises the device. */
 int pcfit_debug_qhull_reasons(int64_t *out16, int reset);
 
 /* Where the hull walks of the hybrid chain start when the caller names no hull_start (and in the scan forms,

@@ -32,6 +32,8 @@ struct Shared {
     int vis[QV], nvis, newf[2], apex, state, reason, n_free, head, nextf;
     double red_d[QT / 64];
     int red_i[QT / 64];
+    double ext_k1[4][QT / 64], ext_k2[4][QT / 64];
+    int ext_at[4][QT / 64];
     double thr[6];               // distround, minvisible, minoutside, distoutside, band, (unused)
     double search[3];            // the simplex search: best determinant so far, the one that ends it, near zero
     int ext[4];
@@ -75,34 +77,55 @@ __device__ inline bool lex_before(const double *x, const double *y, int a, int b
 }
 __device__ inline bool same_point(const double *x, const double *y, int a, int b) { return x[a] == x[b] && y[a] == y[b]; }
 
-// the point of least / greatest value of coordinate c, the lexicographically first among equals (every thread
-// gets the result)
-template <bool GREATEST>
-__device__ int block_arg_extreme(Shared &S, const double *c, const double *x, const double *y, int m)
+// The four coordinate extremes in one pass over the slice: least x, greatest x, least y, greatest y, each the
+// lexicographically first point among equals (what "first in the sorted distinct array" means).  Each is an
+// argmin over a pair key: (x, y), (-x, y), (y, x), (-y, x).  Every thread gets the result.
+struct Key {
+    double k1, k2;
+    int at;
+};
+__device__ inline void key_take(Key &a, double k1, double k2, int at)
+{
+    if (at >= 0 && (a.at < 0 || k1 < a.k1 || (k1 == a.k1 && k2 < a.k2))) { a.k1 = k1; a.k2 = k2; a.at = at; }
+}
+__device__ void block_extremes(Shared &S, const double *x, const double *y, int m, int out[4])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double best = 0.0;
-    int at = -1;
-    auto better = [&](double ob, int oa, double b, int a) {
-        return oa >= 0 && (a < 0 || (GREATEST ? ob > b : ob < b) || (ob == b && lex_before(x, y, oa, a)));
-    };
-    for (int i = tid; i < m; i += QT) {
-        const double v = c[i];
-        if (better(v, i, best, at)) { best = v; at = i; }
+    Key e[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) e[k] = {0.0, 0.0, -1};
+    for (int base = 0; base < m; base += QT * 4) {
+        double px[4], py[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * QT + tid;
+            px[u] = i < m ? x[i] : 0.0;
+            py[u] = i < m ? y[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = base + u * QT + tid, at = i < m ? i : -1;
+            key_take(e[0], px[u], py[u], at);
+            key_take(e[1], -px[u], py[u], at);
+            key_take(e[2], py[u], px[u], at);
+            key_take(e[3], -py[u], px[u], at);
+        }
     }
-    for (int d = 32; d >= 1; d >>= 1) {
-        const double ob = __shfl_xor(best, d);
-        const int oa = __shfl_xor(at, d);
-        if (better(ob, oa, best, at)) { best = ob; at = oa; }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        for (int d = 32; d >= 1; d >>= 1)
+            key_take(e[k], __shfl_xor(e[k].k1, d), __shfl_xor(e[k].k2, d), __shfl_xor(e[k].at, d));
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { S.ext_k1[k][wave] = e[k].k1; S.ext_k2[k][wave] = e[k].k2; S.ext_at[k][wave] = e[k].at; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        Key r = {0.0, 0.0, -1};
+        for (int w = 0; w < QT / 64; w++) key_take(r, S.ext_k1[k][w], S.ext_k2[k][w], S.ext_at[k][w]);
+        out[k] = r.at;
     }
-    __syncthreads();
-    if (lane == 0) { S.red_d[wave] = best; S.red_i[wave] = at; }
-    __syncthreads();
-    best = S.red_d[0];
-    at = S.red_i[0];
-    for (int w = 1; w < QT / 64; w++)
-        if (better(S.red_d[w], S.red_i[w], best, at)) { best = S.red_d[w]; at = S.red_i[w]; }
-    return at;
 }
 
 // The farthest point of each of two classes, over what every thread has seen: (distance, point) per class in
@@ -183,8 +206,9 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     int *const bufs0 = buf_a + off, *const bufs1 = buf_b + off;
 
     // qh_maxmin, qh_detroundoff, qh_maxsimplex
-    const int xlo = block_arg_extreme<false>(S, x, x, y, m), xhi = block_arg_extreme<true>(S, x, x, y, m);
-    const int ylo = block_arg_extreme<false>(S, y, x, y, m), yhi = block_arg_extreme<true>(S, y, x, y, m);
+    int ext4[4];
+    block_extremes(S, x, y, m, ext4);
+    const int xlo = ext4[0], xhi = ext4[1], ylo = ext4[2], yhi = ext4[3];
     if (tid == 0) {
         S.state = 0;
         S.reason = 0;
@@ -326,28 +350,36 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         double fd[3] = {0, 0, 0};
         int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
         bool doubt = false;
+        const double pl[3][3] = {{S.off[f0], S.n0[f0], S.n1[f0]}, {S.off[f1], S.n0[f1], S.n1[f1]}, {S.off[f2], S.n0[f2], S.n1[f2]}};
         auto classify = [&](int i, double &d) -> int {
             const double px = x[i], py = y[i];
+#pragma unroll
             for (int c = 0; c < 3; c++) {
-                d = plane_dist(S, c == 0 ? f0 : c == 1 ? f1 : f2, px, py);
+                d = pl[c][0] + px * pl[c][1] + py * pl[c][2];
                 if (fabs(d) < band) doubt = true;
                 if (d >= thr) return c;
             }
             return 3;
         };
+        // every point's class goes to a byte array in the second index buffer (idle until the first insertion),
+        // so that the placing pass below reads one byte a point instead of its coordinates
+        unsigned char *cls = reinterpret_cast<unsigned char *>(bufs1);
         for (int base = 0; base < m; base += QT) {
             const int i = base + tid;
             int c = 3;
             double d = 0.0;
             if (i < m && !same_point(x, y, i, e0) && !same_point(x, y, i, e1) && !same_point(x, y, i, e2)) c = classify(i, d);
+            if (i < m) cls[i] = (unsigned char)c;
             for (int k = 0; k < 3; k++) {
                 const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
                 if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
             }
-            if (c < 3) {
-                if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = i; ft[c] = 0; }
-                else if (d == fd[c] && !same_point(x, y, i, fi[c])) ft[c] = 1;
-            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)                    // (constant indices: the arrays stay in registers)
+                if (c == k) {
+                    if (fi[k] < 0 || d > fd[k]) { fd[k] = d; fi[k] = i; ft[k] = 0; }
+                    else if (d == fd[k] && !same_point(x, y, i, fi[k])) ft[k] = 1;
+                }
         }
         if (doubt) { S.state = 2; S.reason = 3; }
         // the farthest point of each of the three sets
@@ -399,9 +431,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         int *A = bufs0;
         for (int base = 0; base < m; base += QT) {
             const int i = base + tid;
-            int c = 3;
-            double d = 0.0;
-            if (i < m && !same_point(x, y, i, e0) && !same_point(x, y, i, e1) && !same_point(x, y, i, e2)) c = classify(i, d);
+            const int c = i < m ? (int)cls[i] : 3;
             for (int k = 0; k < 3; k++) {
                 const int slot = wave_slot(&S.c0[k], c == k);
                 if (c == k) A[S.c1[k] + slot] = i;
@@ -410,6 +440,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         __syncthreads();
     }
     // qh_buildhull
+    unsigned long long visits = 0;
+    int steps = 0;
     for (int step = 0; step < m + 8; step++) {
         if (tid == 0) {
             const double minvisible = S.thr[1], band = S.thr[4];
@@ -443,6 +475,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                     }
                 }
                 S.nvis = nvis;
+                steps++;
+                for (int k = 0; k < nvis; k++) visits += (unsigned long long)S.total[S.vis[k]];
                 // qh_makenew_simplicial: one facet per horizon ridge, the apex first
                 int n_new = 0;
                 for (int k = 0; k < nvis && S.state == 0; k++) {
@@ -491,8 +525,10 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
         const double apex_x = x[apex], apex_y = y[apex];
         const double minoutside = S.thr[2], band = S.thr[4];
-        double fd[2] = {0, 0};
-        int fi[2] = {-1, -1}, ft[2] = {0, 0};
+        const double a0_n0 = S.n0[a0], a0_n1 = S.n1[a0], a0_off = S.off[a0];
+        const double a1_n0 = S.n0[a1], a1_n1 = S.n1[a1], a1_off = S.off[a1];
+        double fd0 = 0.0, fd1 = 0.0;
+        int fi0 = -1, fi1 = -1, ft0 = 0, ft1 = 0;
         bool doubt = false;
         for (int k = 0; k < nvis; k++) {
             const int v = S.vis[k], np = S.np[v];
@@ -501,39 +537,52 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 const int lo = (int)(word & IDX_MASK), from = (int)(word >> 31), cnt = S.pcnt[v][q], slot = k * QP + q;
                 const int *src = from ? bufs1 : bufs0;
                 int *dst = from ? bufs0 : bufs1;
-                for (int base = 0; base < cnt; base += QT) {
-                    const int i = base + tid;
-                    int c = 2, p = -1;
-                    double d = 0.0;
-                    if (i < cnt) {
-                        p = src[lo + i];
-                        const double px = x[p], py = y[p];
-                        if (px != apex_x || py != apex_y) {
-                            d = plane_dist(S, a0, px, py);
+                // four points a thread and turn: the gathers of their coordinates are in flight together
+                for (int base = 0; base < cnt; base += QT * 4) {
+                    int p[4];
+                    double px[4], py[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = base + u * QT + tid;
+                        p[u] = i < cnt ? src[lo + i] : -1;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        px[u] = p[u] >= 0 ? x[p[u]] : apex_x;
+                        py[u] = p[u] >= 0 ? y[p[u]] : apex_y;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int c = 2;
+                        double d = 0.0;
+                        if (px[u] != apex_x || py[u] != apex_y) {
+                            d = a0_off + px[u] * a0_n0 + py[u] * a0_n1;
                             if (fabs(d) < band) doubt = true;
                             if (d >= minoutside) c = 0;
                             else {
-                                d = plane_dist(S, a1, px, py);
+                                d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
                                 if (fabs(d) < band) doubt = true;
                                 if (d >= minoutside) c = 1;
                             }
                         }
-                    }
-                    const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);
-                    if (c == 0) dst[lo + s0] = p;
-                    if (c == 1) dst[lo + cnt - 1 - s1] = p;
-                    if (c < 2) {
-                        if (fi[c] < 0 || d > fd[c]) { fd[c] = d; fi[c] = p; ft[c] = 0; }
-                        else if (d == fd[c] && !same_point(x, y, i, fi[c])) ft[c] = 1;
+                        const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);
+                        if (c == 0) dst[lo + s0] = p[u];
+                        if (c == 1) dst[lo + cnt - 1 - s1] = p[u];
+                        if (c == 0) {
+                            if (fi0 < 0 || d > fd0) { fd0 = d; fi0 = p[u]; ft0 = 0; }
+                            else if (d == fd0 && !same_point(x, y, p[u], fi0)) ft0 = 1;
+                        } else if (c == 1) {
+                            if (fi1 < 0 || d > fd1) { fd1 = d; fi1 = p[u]; ft1 = 0; }
+                            else if (d == fd1 && !same_point(x, y, p[u], fi1)) ft1 = 1;
+                        }
                     }
                 }
             }
         }
         double od[2];
         int oi[2], ot[2];
-        block_far(S, x, y, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
-        for (int c = 0; c < 2; c++)
-            if (ft[c] && fi[c] >= 0 && fd[c] == od[c]) doubt = true;
+        block_far(S, x, y, fd0, fi0, fd1, fi1, od, oi, ot);
+        if ((ft0 && fi0 >= 0 && fd0 == od[0]) || (ft1 && fi1 >= 0 && fd1 == od[1])) doubt = true;
         if (doubt) { S.state = 2; S.reason = 10; }
         __syncthreads();
         if (tid == 0 && S.state == 0) {
@@ -581,6 +630,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         } else if (S.state == 0)
             S.reason = 13;
         if (out == QHULL_DEFER) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
+        atomicAdd(&g_qhull_reason[14], (unsigned long long)steps);
+        atomicAdd(&g_qhull_reason[15], visits);
         start[s] = out;
         if (start_xy && out >= 0) { start_xy[2 * s] = x[out]; start_xy[2 * s + 1] = y[out]; }
     }

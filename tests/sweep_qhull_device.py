@@ -64,10 +64,10 @@ def main(rounds=20, seed=0):
                 break
         slices += len(off) - 1
         points += int(off[-1])
-        handed += int(why.sum())
+        handed += int(why[:14].sum())
     print(f"{rounds} rounds, {slices} slices, {points} points, {time.time() - t0:.0f} s: {bad} differences "
           f"(and {open_} on slices the host replay is not sure of); "
-          f"handed back to the host {handed} ({why_all.tolist()})")
+          f"handed back to the host {handed} ({why_all[:14].tolist()})")
     return bad
 
 

@@ -204,7 +204,7 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
     deferred = got == -3
     assert np.array_equal(got[~deferred], g["first"][~deferred])
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
-    assert int(why.sum()) == int(deferred.sum())
+    assert int(why[:14].sum()) == int(deferred.sum())          # ([14], [15]: insertions and point visits)
     # handed back: decisions near a threshold (integer grids, points on a square's edge, clusters far from the
     # origin) and ties; on rings, disks, clouds, flat ellipses, arcs and the cylinder's slabs the kernel answers itself
     plain = np.array([c[0] in ("ring", "disk", "gauss", "ringf32", "slab", "ellipse", "arc", "small") for c in cases])

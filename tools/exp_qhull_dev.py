@@ -1,0 +1,40 @@
+"""Time of the device replay of Qhull's construction on slices of the bench's kind, with the number of insertions and
+of point visits it took (needs a GPU).  python tools/exp_qhull_dev.py [slices] [points per slice]"""
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, ".")
+from pointcloud_amd import _ffi as F
+
+S, n = (int(a) for a in (sys.argv[1:3] + ["2000", "50000"])[:2])
+g = np.random.default_rng(0)
+dev = torch.device("cuda", 0)
+th = torch.rand(S * n, dtype=torch.float64, device=dev) * (2 * np.pi)
+r = 10 + 0.05 * torch.randn(S * n, dtype=torch.float64, device=dev)
+bad = torch.rand(S * n, device=dev) < 0.1
+r = torch.where(bad, torch.rand(S * n, dtype=torch.float64, device=dev) * 14, r)
+x, y = 3 + r * torch.cos(th), -2 + r * torch.sin(th)
+off = torch.arange(S + 1, dtype=torch.int64, device=dev) * n
+p = lambda a: C.c_void_p(a.data_ptr())
+# hull sizes from the library (sorted route, once)
+h = F.unique_hull_batch(x.cpu().numpy(), y.cpu().numpy(), off.cpu().numpy())
+nh = torch.from_numpy(h["n_hull"]).to(dev)
+scratch = torch.empty(S * n * 8, dtype=torch.uint8, device=dev)
+start = torch.empty(S, dtype=torch.int64, device=dev)
+why = np.zeros(16, np.int64)
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+for rep in range(3):
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    F.check(F.lib().pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 8,
+                                                p(start), st))
+    e1.record()
+    torch.cuda.synchronize()
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    print(f"{e0.elapsed_time(e1):.3f} ms; per slice: {why[14] / S:.1f} insertions, {why[15] / S / n:.2f} visits per point after the "
+          f"first partition; handed back {int(why[:14].sum())}; mean hull {float(nh.double().mean()):.1f}")
