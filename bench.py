@@ -224,9 +224,11 @@ def extra_configs(L, dev, stream):
         # for element
         F.set_hull_order("qhull")
         try:
-            t_q = time.perf_counter()
             res_q = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
-            t_q = time.perf_counter() - t_q
+            t_q = time.perf_counter()
+            for _ in range(3):
+                res_q = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0)
+            t_q = (time.perf_counter() - t_q) / 3
         finally:
             F.set_hull_order("canonical")
     okw = res["status"] == 0

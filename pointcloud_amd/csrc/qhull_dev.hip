@@ -351,35 +351,45 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
         bool doubt = false;
         const double pl[3][3] = {{S.off[f0], S.n0[f0], S.n1[f0]}, {S.off[f1], S.n0[f1], S.n1[f1]}, {S.off[f2], S.n0[f2], S.n1[f2]}};
-        auto classify = [&](int i, double &d) -> int {
-            const double px = x[i], py = y[i];
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                d = pl[c][0] + px * pl[c][1] + py * pl[c][2];
-                if (fabs(d) < band) doubt = true;
-                if (d >= thr) return c;
-            }
-            return 3;
-        };
         // every point's class goes to a byte array in the second index buffer (idle until the first insertion),
         // so that the placing pass below reads one byte a point instead of its coordinates
         unsigned char *cls = reinterpret_cast<unsigned char *>(bufs1);
-        for (int base = 0; base < m; base += QT) {
-            const int i = base + tid;
-            int c = 3;
-            double d = 0.0;
-            if (i < m && !same_point(x, y, i, e0) && !same_point(x, y, i, e1) && !same_point(x, y, i, e2)) c = classify(i, d);
-            if (i < m) cls[i] = (unsigned char)c;
-            for (int k = 0; k < 3; k++) {
-                const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
-                if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
+        const double e0x = x[e0], e0y = y[e0], e1x = x[e1], e1y = y[e1], e2x = x[e2], e2y = y[e2];
+        for (int base = 0; base < m; base += QT * 4) {
+            double px[4], py[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + u * QT + tid;
+                px[u] = i < m ? x[i] : e0x;
+                py[u] = i < m ? y[i] : e0y;
             }
 #pragma unroll
-            for (int k = 0; k < 3; k++)                    // (constant indices: the arrays stay in registers)
-                if (c == k) {
-                    if (fi[k] < 0 || d > fd[k]) { fd[k] = d; fi[k] = i; ft[k] = 0; }
-                    else if (d == fd[k] && !same_point(x, y, i, fi[k])) ft[k] = 1;
+            for (int u = 0; u < 4; u++) {
+                const int i = base + u * QT + tid;
+                int c = 3;
+                double d = 0.0;
+                const bool vertex = (px[u] == e0x && py[u] == e0y) || (px[u] == e1x && py[u] == e1y) ||
+                                    (px[u] == e2x && py[u] == e2y);
+                if (!vertex) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        if (c != 3) continue;
+                        d = pl[k][0] + px[u] * pl[k][1] + py[u] * pl[k][2];
+                        if (fabs(d) < band) doubt = true;
+                        if (d >= thr) c = k;
+                    }
                 }
+                if (i < m) cls[i] = (unsigned char)c;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
+                    if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
+                    if (c == k) {
+                        if (fi[k] < 0 || d > fd[k]) { fd[k] = d; fi[k] = i; ft[k] = 0; }
+                        else if (d == fd[k] && !same_point(x, y, i, fi[k])) ft[k] = 1;
+                    }
+                }
+            }
         }
         if (doubt) { S.state = 2; S.reason = 3; }
         // the farthest point of each of the three sets
