@@ -18,7 +18,7 @@ def rel(a, b):
 
 
 def _same_as_cpu(pts, got, zc):
-    want, _, warn = R.process_slice(pts, zc)
+    want, _, warn = R.process_slice(pts, zc, hull_start="qhull")         # hulls walked as scipy's ConvexHull does
     assert warn is None
     assert got["z_center"] == zc
     assert got["n_points_slice"] == want["n_points_slice"] and got["n_edge"] == want["n_edge"]
@@ -36,7 +36,7 @@ def test_fifty_million_point_scans_alone_and_as_a_batch():
     run dict for dict, two windows of each of the others are replayed."""
     from pointcloud_amd import Config, CylinderAnalyzer, DeviceScan, sharding
     n, S = 50_000_000, 1000
-    az = CylinderAnalyzer(Config(hull_order="canonical"))       # the CPU replay below walks hulls from their lexicographic minimum
+    az = CylinderAnalyzer(Config())
     pts = R.make_cylinder(n, S, seed=100, outlier_frac=0.0)
     with DeviceScan(pts) as scan:
         assert (scan.z_min, scan.z_max) == (0.0, 2.0 * S)
