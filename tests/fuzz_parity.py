@@ -11,6 +11,7 @@ import torch  # noqa: F401  (first, so that the process runs on ONE HIP runtime:
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import native as N           # noqa: E402
+from oracle import qhull2d as Q
 from oracle import ref_np as R           # noqa: E402
 from pointcloud_amd import _ffi as F     # noqa: E402
 
@@ -212,13 +213,17 @@ def hybrid_round(seed):
     trials = int(g.choice([50, 200]))
     # (without the list of distinct points the hull kernel drops interior points before its sort)
     want_unique = bool(g.random() < 0.4)
-    h = F.hybrid_batch(x, y, off, max_trials=trials, use_hull=use_hull, want_profile=False, want_unique=want_unique)
+    # hulls walked from their lexicographic minimum, or as scipy's ConvexHull walks them (the replay of Qhull's
+    # construction: over the sorted distinct points when they are wanted, over the slices as they are otherwise)
+    qhull = bool(use_hull and g.random() < 0.5)
+    with F.hull_order("qhull" if qhull else "canonical"):
+        h = F.hybrid_batch(x, y, off, max_trials=trials, use_hull=use_hull, want_profile=False, want_unique=want_unique)
     for s, xy in enumerate(sets):
-        tag = f"[{kinds[s]} n={len(xy)} hull={use_hull} unique={want_unique}]"
+        tag = f"[{kinds[s]} n={len(xy)} hull={use_hull} unique={want_unique} qhull={qhull}]"
         if use_hull is False and len(xy) > 1024:
             continue                                      # (the restatement's RANSAC loop is too slow for these)
         ref = R.hybrid_fit(np.column_stack([xy, np.zeros(len(xy))]), 0.0, 1.0, max_trials=trials,
-                           use_hull_vertices_only=use_hull) if len(xy) else None
+                           use_hull_vertices_only=use_hull, hull_start="qhull" if qhull else None) if len(xy) else None
         ok = h["status"][s] == 0
         if (ref is not None) != ok:
             if kinds[s] not in ("line", "same"):
@@ -228,7 +233,9 @@ def hybrid_round(seed):
             continue
         c0, c1 = h["cand_offsets"][s], h["cand_offsets"][s + 1]
         if not np.array_equal(np.stack([h["cand_x"][c0:c1], h["cand_y"][c0:c1]], 1), ref["candidates_xy"]):
-            note(seed, s, "hybrid candidates", tag)
+            # (points exactly in line: Qhull merges facets there, the replay's start vertex is a best effort)
+            if not (qhull and not Q.vertices(R.unique_rows(xy))[1]):
+                note(seed, s, "hybrid candidates", tag)
         elif not np.array_equal(h["mask"][c0:c1], ref["inlier_mask"]):
             note(seed, s, "hybrid inlier mask", tag)
         else:
