@@ -3,9 +3,12 @@
 // LDS; the work that grows with the slice - the partition of the points into outside sets and of the outside
 // sets of visible facets among the two new facets, and the search of every set's farthest point - runs
 // across the workgroup.  The order of the points inside an outside set is not kept (it decides nothing but ties).
-// The kernel handles the plain course of the construction only: whenever a decision falls inside Qhull's
-// roundoff bands, a distance ties for the farthest point, the initial simplex is flat, or one of the fixed
-// capacities below runs out, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
+// The kernel follows the host replay decision for decision, except for the points that lie below both new
+// facets of an insertion: it drops them, where Qhull goes on to search the horizon and may, for a point a few
+// roundoff units from a new facet, find another facet for it or change its search mode for the points that
+// follow.  Whenever a point comes that close (within 8 roundoff units of a new facet without being clearly
+// outside), two points tie for the farthest of a set, or one of the fixed capacities below runs out, the slice
+// is handed back (start = QHULL_DEFER) and the host replay decides it.
 #include "pcfit_internal.h"
 
 namespace pcfit {
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     {
         const int f0 = S.vis[0], f1 = S.vis[1], f2 = S.vis[2];
         const int e0 = S.ext[0], e1 = S.ext[1], e2 = S.ext[2];
-        const double thr = S.thr[3], band = S.thr[4];
+        const double thr = S.thr[3];
         double fd[3] = {0, 0, 0};
         int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
         bool doubt = false;
@@ -371,13 +374,16 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 const bool vertex = (px[u] == e0x && py[u] == e0y) || (px[u] == e1x && py[u] == e1y) ||
                                     (px[u] == e2x && py[u] == e2y);
                 if (!vertex) {
+                    bool close = false;
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         if (c != 3) continue;
                         d = pl[k][0] + px[u] * pl[k][1] + py[u] * pl[k][2];
-                        if (fabs(d) < band) doubt = true;
                         if (d >= thr) c = k;
+                        else if (d > -thr) close = true;
                     }
+                    // outside of no facet, yet within reach of one: Qhull looks at such a point once more
+                    if (c == 3 && close) doubt = true;
                 }
                 if (i < m) cls[i] = (unsigned char)c;
 #pragma unroll
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     int steps = 0;
     for (int step = 0; step < m + 8; step++) {
         if (tid == 0) {
-            const double minvisible = S.thr[1], band = S.thr[4];
+            const double minvisible = S.thr[1];
             while (S.nextf != 0 && S.total[S.nextf] == 0) S.nextf = S.next[S.nextf];           // qh_nextfurthest
             if (S.nextf == 0)
                 S.state = 1;
@@ -474,7 +480,6 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                         const int g = j ? S.nb1[v] : S.nb0[v];
                         if (S.visible[g]) continue;
                         const double d = plane_dist(S, g, ax, ay);
-                        if (fabs(d) < band) { S.state = 2; S.reason = 5; break; }
                         if (d > minvisible) {
                             if (nvis == QV) { S.state = 2; S.reason = 6; break; }
                             list_remove(S, g);
@@ -515,16 +520,6 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 if (S.state == 0) {
                     S.nb1[S.newf[0]] = (short)S.newf[1];
                     S.nb1[S.newf[1]] = (short)S.newf[0];
-                    // where Qhull's default merging would look twice
-                    for (int k = 0; k < 2; k++) {
-                        const int a = S.newf[k], g = S.nb0[a], b = S.newf[1 - k];
-                        const int w = S.v0[g] == S.v1[a] ? S.v1[g] : S.v0[g], r = S.v1[b];
-                        if (plane_dist(S, a, x[w], y[w]) > -band || plane_dist(S, g, ax, ay) > -band ||
-                            plane_dist(S, a, x[r], y[r]) > -band) {
-                            S.state = 2;
-                            S.reason = 9;
-                        }
-                    }
                     for (int k = 0; k < QV * QP; k++) S.c0[k] = S.c1[k] = 0;
                 }
             }
@@ -534,7 +529,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
         const double apex_x = x[apex], apex_y = y[apex];
-        const double minoutside = S.thr[2], band = S.thr[4];
+        const double minoutside = S.thr[2], reach = S.thr[3];
         const double a0_n0 = S.n0[a0], a0_n1 = S.n1[a0], a0_off = S.off[a0];
         const double a1_n0 = S.n0[a1], a1_n1 = S.n1[a1], a1_off = S.off[a1];
         double fd0 = 0.0, fd1 = 0.0;
@@ -567,12 +562,14 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                         double d = 0.0;
                         if (px[u] != apex_x || py[u] != apex_y) {
                             d = a0_off + px[u] * a0_n0 + py[u] * a0_n1;
-                            if (fabs(d) < band) doubt = true;
-                            if (d >= minoutside) c = 0;
-                            else {
+                            if (d >= minoutside) {
+                                c = 0;
+                                if (d < reach) doubt = true;        // (Qhull's other search mode may prefer the second facet)
+                            } else {
+                                const double d0 = d;
                                 d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
-                                if (fabs(d) < band) doubt = true;
                                 if (d >= minoutside) c = 1;
+                                else if (d0 > -reach || d > -reach) doubt = true;    // below both, but barely
                             }
                         }
                         const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);

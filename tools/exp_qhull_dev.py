@@ -1,4 +1,4 @@
-"""Time of the device replay of Qhull's construction on slices of the bench's kind, with the number of insertions and
+"""Time of the device replay (optionally of a cylinder far from the origin: [x0 y0]) of Qhull's construction on slices of the bench's kind, with the number of insertions and
 of point visits it took (needs a GPU).  python tools/exp_qhull_dev.py [slices] [points per slice]"""
 import ctypes as C
 import sys
@@ -11,13 +11,14 @@ sys.path.insert(0, ".")
 from pointcloud_amd import _ffi as F
 
 S, n = (int(a) for a in (sys.argv[1:3] + ["2000", "50000"])[:2])
+shift = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (3.0, -2.0)      # where the cylinder stands
 g = np.random.default_rng(0)
 dev = torch.device("cuda", 0)
 th = torch.rand(S * n, dtype=torch.float64, device=dev) * (2 * np.pi)
 r = 10 + 0.05 * torch.randn(S * n, dtype=torch.float64, device=dev)
 bad = torch.rand(S * n, device=dev) < 0.1
 r = torch.where(bad, torch.rand(S * n, dtype=torch.float64, device=dev) * 14, r)
-x, y = 3 + r * torch.cos(th), -2 + r * torch.sin(th)
+x, y = shift[0] + r * torch.cos(th), shift[1] + r * torch.sin(th)
 off = torch.arange(S + 1, dtype=torch.int64, device=dev) * n
 p = lambda a: C.c_void_p(a.data_ptr())
 # hull sizes from the library (sorted route, once)
