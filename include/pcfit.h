@@ -338,7 +338,7 @@ int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *o
  * PCFIT_HULL_START_QHULL): one workgroup per slice.  start[s] = the first vertex, -1 where there is no hull or
  * the slice was not selected, PCFIT_QHULL_START_DEFER where the kernel met anything but the plain course of
  * the construction (a decision inside Qhull's roundoff bands, a tie for the farthest point, a flat initial
- * simplex, more than 511 facets alive at once) - those slices are for pcfit_qhull_order_batch.
+ * simplex, more than 479 facets alive at once) - those slices are for pcfit_qhull_order_batch.
  * scratch: total_points * 8 bytes of device memory. */
 #define PCFIT_QHULL_START_DEFER (-3)
 int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,

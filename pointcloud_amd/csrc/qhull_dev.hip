@@ -3,12 +3,13 @@
 // LDS; the work that grows with the slice - the partition of the points into outside sets and of the outside
 // sets of visible facets among the two new facets, and the search of every set's farthest point - runs
 // across the workgroup.  The order of the points inside an outside set is not kept (it decides nothing but ties).
-// The kernel follows the host replay decision for decision, except for the points that lie below both new
-// facets of an insertion: it drops them, where Qhull goes on to search the horizon and may, for a point a few
-// roundoff units from a new facet, find another facet for it or change its search mode for the points that
-// follow.  Whenever a point comes that close (within 8 roundoff units of a new facet without being clearly
-// outside), two points tie for the farthest of a set, or one of the fixed capacities below runs out, the slice
-// is handed back (start = QHULL_DEFER) and the host replay decides it.
+// The kernel follows the host replay decision for decision.  Points that lie below both new facets of an
+// insertion by less than a roundoff unit are listed during the parallel pass and taken through Qhull's horizon
+// search by the one thread afterwards (whatever mode Qhull's search is in by then, it ends in that walk).  Where
+// the order inside a set would matter - two points tie for the farthest of a set, a point lies 4 to 8 roundoff
+// units above the first new facet, two facets get their first point through the horizon search in one
+// insertion - or one of the fixed capacities below runs out, or the replay ends with another number of vertices
+// than the strict hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
 #include "pcfit_internal.h"
 
 namespace pcfit {
@@ -16,14 +17,16 @@ __device__ unsigned long long g_qhull_reason[16];      // slices handed back, by
 namespace {
 
 constexpr int QT = 256;          // threads of a workgroup
-constexpr int QF = 512;          // live facets of a slice (slot 0 is the list's tail)
-constexpr int QP = 6;            // pieces an outside set may lie in
-constexpr int QV = 8;            // visible facets of one insertion
+constexpr int QF = 480;          // live facets of a slice (slot 0 is the list's tail)
+constexpr int QP = 5;            // pieces an outside set may lie in
+constexpr int QV = 6;            // visible facets of one insertion
+constexpr int QU = 32;           // points of one insertion that go through the horizon search
 constexpr int64_t QHULL_DEFER = QHULL_START_DEFER;
 constexpr unsigned IDX_MASK = 0x7fffffffu;      // a piece's start; the top bit names the buffer it lies in
 
 struct Shared {
     double n0[QF], n1[QF], off[QF];
+    double far_d[QF];
     int v0[QF], v1[QF], total[QF], far_idx[QF];
     int plo[QF][QP], pcnt[QF][QP];
     short nb0[QF], nb1[QF], prev[QF], next[QF], free_slot[QF];
@@ -33,6 +36,11 @@ struct Shared {
     double wave_d[2][QT / 64];
     int wave_i[2][QT / 64], wave_tie[2][QT / 64];
     int vis[QV], nvis, newf[2], apex, state, reason, n_free, head, nextf;
+    // points below both new facets by less than a roundoff unit: Qhull searches the horizon for them
+    int unc_p[QU], unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
+    double unc_d[QU];
+    unsigned short visit[QF], visit_id;
+    short copl[64];
     double red_d[QT / 64];
     int red_i[QT / 64];
     double ext_k1[4][QT / 64], ext_k2[4][QT / 64];
@@ -305,6 +313,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
             // qh_createsimplex, qh_initialhull
             for (int k = 0; k < QF; k++) S.free_slot[k] = (short)(QF - 1 - k);      // slots QF-1 .. 1 (0 is the tail)
             S.n_free = QF - 1;
+            S.visit_id = 0;
+            for (int k = 0; k < QF; k++) S.visit[k] = 0;
             S.head = S.nextf = 0;
             S.prev[0] = -1;
             S.next[0] = 0;
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     {
         const int f0 = S.vis[0], f1 = S.vis[1], f2 = S.vis[2];
         const int e0 = S.ext[0], e1 = S.ext[1], e2 = S.ext[2];
-        const double thr = S.thr[3];
+        const double thr = S.thr[3], minoutside = S.thr[2];
         double fd[3] = {0, 0, 0};
         int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
         bool doubt = false;
@@ -374,16 +384,18 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 const bool vertex = (px[u] == e0x && py[u] == e0y) || (px[u] == e1x && py[u] == e1y) ||
                                     (px[u] == e2x && py[u] == e2y);
                 if (!vertex) {
-                    bool close = false;
+                    double most = -1e300;
+                    int most_k = 3;
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         if (c != 3) continue;
                         d = pl[k][0] + px[u] * pl[k][1] + py[u] * pl[k][2];
                         if (d >= thr) c = k;
-                        else if (d > -thr) close = true;
+                        else if (d > most) { most = d; most_k = k; }
                     }
-                    // outside of no facet, yet within reach of one: Qhull looks at such a point once more
-                    if (c == 3 && close) doubt = true;
+                    // outside of no facet by the first threshold: Qhull looks at such a point once more and gives
+                    // it to the facet it is farthest from if that is outside by the lower threshold
+                    if (c == 3 && most >= minoutside) { c = most_k; d = most; }
                 }
                 if (i < m) cls[i] = (unsigned char)c;
 #pragma unroll
@@ -420,6 +432,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 if (far_t[c]) { S.state = 2; S.reason = 4; }
                 S.total[fs[c]] = cnt[c];
                 S.far_idx[fs[c]] = far_i[c];
+                S.far_d[fs[c]] = far_d[c];
                 if (cnt[c] > 0) { S.np[fs[c]] = 1; S.plo[fs[c]][0] = at; S.pcnt[fs[c]][0] = cnt[c]; }
                 S.c1[c] = at;                      // where the set's run starts
                 S.c0[c] = 0;
@@ -520,7 +533,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 if (S.state == 0) {
                     S.nb1[S.newf[0]] = (short)S.newf[1];
                     S.nb1[S.newf[1]] = (short)S.newf[0];
-                    for (int k = 0; k < QV * QP; k++) S.c0[k] = S.c1[k] = 0;
+                    for (int k = 0; k < QV * QP; k++) S.c0[k] = S.c1[k] = S.gap_used[k] = 0;
+                    S.n_unc = 0;
                 }
             }
         }
@@ -529,7 +543,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
         const double apex_x = x[apex], apex_y = y[apex];
-        const double minoutside = S.thr[2], reach = S.thr[3];
+        const double minoutside = S.thr[2], reach = S.thr[3], distround = S.thr[0];
         const double a0_n0 = S.n0[a0], a0_n1 = S.n1[a0], a0_off = S.off[a0];
         const double a1_n0 = S.n0[a1], a1_n1 = S.n1[a1], a1_off = S.off[a1];
         double fd0 = 0.0, fd1 = 0.0;
@@ -569,7 +583,16 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                                 const double d0 = d;
                                 d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
                                 if (d >= minoutside) c = 1;
-                                else if (d0 > -reach || d > -reach) doubt = true;    // below both, but barely
+                                else if (fmax(d0, d) >= -distround) {
+                                    // below both by less than a roundoff unit: the horizon search, after the pass
+                                    const int at = atomicAdd(&S.n_unc, 1);
+                                    if (at < QU) {
+                                        S.unc_p[at] = p[u];
+                                        S.unc_slot[at] = slot;
+                                        S.unc_from[at] = d > d0 ? a1 : a0;
+                                        S.unc_d[at] = fmax(d0, d);
+                                    }
+                                }
                             }
                         }
                         const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);
@@ -615,6 +638,71 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
             }
             S.far_idx[a0] = oi[0];
             S.far_idx[a1] = oi[1];
+            S.far_d[a0] = od[0];
+            S.far_d[a1] = od[1];
+            // qh_findbesthorizon for the points that lie below both new facets by less than a roundoff unit
+            // (whatever mode Qhull's search is in by then, it ends in this walk): over neighbours whose distance
+            // is no more than the search distance below the best one found; the point joins the facet found if it
+            // lies outside of it, and a facet that had no outside points goes to the end of the list
+            if (S.n_unc > QU) { S.state = 2; S.reason = 10; }
+            int moved = 0;
+            const double searchdist = S.thr[0] * 2 + S.thr[1];
+            for (int k = 0; k < S.n_unc && S.state == 0; k++) {
+                const int p = S.unc_p[k];
+                const double px = x[p], py = y[p];
+                double bestdist = S.unc_d[k], minsearch = bestdist - searchdist;
+                int bestf = S.unc_from[k], facet = bestf, nextfacet = 0, size = 0;
+                const unsigned short id = ++S.visit_id;
+                S.visit[bestf] = id;
+                while (true) {
+                    for (int j = 0; j < 2; j++) {
+                        const int nb = j ? S.nb1[facet] : S.nb0[facet];
+                        if (S.visit[nb] == id || S.visible[nb]) continue;
+                        S.visit[nb] = id;
+                        const double d = plane_dist(S, nb, px, py);
+                        if (d > bestdist) {
+                            minsearch = d - searchdist;
+                            if (d > bestdist + searchdist) size = 0;
+                            bestf = nb;
+                            bestdist = d;
+                        } else if (d < minsearch)
+                            continue;
+                        if (nextfacet) {
+                            if (size == 0) { S.copl[0] = (short)nextfacet; size = 1; }
+                            else if (size < 64) S.copl[size++] = (short)nextfacet;
+                        }
+                        nextfacet = nb;
+                    }
+                    facet = nextfacet;
+                    if (facet) nextfacet = 0;
+                    else if (size == 0) break;
+                    else facet = S.copl[--size];
+                }
+                if (bestdist < minoutside) continue;                // not outside of anything: dropped
+                if (bestf == a0 || bestf == a1) { S.state = 2; S.reason = 10; break; }
+                if (S.total[bestf] == 0) {
+                    if (moved) { S.state = 2; S.reason = 10; break; }       // (two such moves: their order is the sets')
+                    moved = 1;
+                    list_remove(S, bestf);
+                    list_append(S, bestf);
+                    S.far_idx[bestf] = p;
+                    S.far_d[bestf] = bestdist;
+                } else if (S.far_d[bestf] < bestdist) {
+                    S.far_idx[bestf] = p;
+                    S.far_d[bestf] = bestdist;
+                }
+                if (S.np[bestf] == QP) { S.state = 2; S.reason = 11; break; }
+                // a one-point piece in the gap the dropped points left in the piece this point came from
+                const int slot = S.unc_slot[k], v = S.vis[slot / QP], q = slot % QP;
+                const unsigned word = (unsigned)S.plo[v][q];
+                const int lo = (int)(word & IDX_MASK), to = (int)(word >> 31) ^ 1;
+                const int at = lo + S.c0[slot] + S.gap_used[slot]++;
+                (to ? bufs1 : bufs0)[at] = p;
+                S.plo[bestf][S.np[bestf]] = (int)((unsigned)at | ((unsigned)to << 31));
+                S.pcnt[bestf][S.np[bestf]] = 1;
+                S.np[bestf]++;
+                S.total[bestf]++;
+            }
             // qh_deletevisible
             for (int k = 0; k < nvis; k++) {
                 const int v = S.vis[k];

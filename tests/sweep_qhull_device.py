@@ -16,14 +16,22 @@ from pointcloud_amd import _ffi as F            # noqa: E402
 
 def main(rounds=20, seed=0):
     gen = np.random.default_rng(seed)
-    bad = open_ = slices = points = handed = 0
+    bad = open_ = slices = points = handed = quant = 0
     why_all = np.zeros(16, np.int64)
     t0 = time.time()
     for r in range(rounds):
         xs, ys, off = [], [], [0]
         for k in range(int(gen.integers(50, 600))):
-            xy = make_case(KINDS[int(gen.integers(len(KINDS)))],
-                           int(gen.choice([3, 4, 6, 10, 30, 200, 1500, 8192, 9000, 30000, 70000])), int(gen.integers(1 << 30)))
+            n = int(gen.choice([3, 4, 6, 10, 30, 200, 1500, 8192, 9000, 30000, 70000]))
+            if gen.random() < 0.25:
+                # a ring with coordinates rounded as in a text file: points exactly in line at the extremes
+                th = gen.uniform(0, 2 * np.pi, n)
+                rad = 10 + gen.normal(0, 0.005, n)
+                xy = np.unique(np.round(np.stack([3 + rad * np.cos(th), -2 + rad * np.sin(th)], 1), int(gen.choice([2, 3, 3, 4]))),
+                               axis=0)
+                quant += 1
+            else:
+                xy = make_case(KINDS[int(gen.integers(len(KINDS)))], n, int(gen.integers(1 << 30)))
             if gen.random() < 0.2:                       # duplicates and another order: the library sorts and dedups
                 xy = np.concatenate([xy, xy[gen.integers(0, len(xy), len(xy) // 3 + 1)]])
             xy = xy[gen.permutation(len(xy))]
@@ -44,6 +52,11 @@ def main(rounds=20, seed=0):
             same = walk[0] == host["start"][s] and (not host["sure"][s] or np.array_equal(walk, hw))
             if not same and not host["sure"][s]:
                 open_ += 1          # points exactly in line: the host replay's answer is a best effort itself
+                if os.path.isdir("gpurun_out"):
+                    nu = int(h["n_unique"][s])
+                    np.save(f"gpurun_out/qhull_open_{seed}_{r}_{s}.npy",
+                            np.stack([h["ux"][off[s]:off[s] + nu], h["uy"][off[s]:off[s] + nu]], 1))
+                    print("open: round", r, "slice", s, "distinct points", nu, "device route", walk[:3], "host", hw[:3])
             elif not same:
                 bad += 1
                 print("round", r, "slice", s, "points", off[s + 1] - off[s], "device route", walk[:4], "host", hw[:4],
@@ -66,7 +79,7 @@ def main(rounds=20, seed=0):
         points += int(off[-1])
         handed += int(why[:14].sum())
     print(f"{rounds} rounds, {slices} slices, {points} points, {time.time() - t0:.0f} s: {bad} differences "
-          f"(and {open_} on slices the host replay is not sure of); "
+          f"(and {open_} on slices the host replay is not sure of); {quant} slices with rounded coordinates; "
           f"handed back to the host {handed} ({why_all[:14].tolist()})")
     return bad
 
