@@ -9,8 +9,9 @@ orientation), so the order follows from the list Qhull's incremental constructio
 restates that construction for points in general position, from Qhull's published algorithm (quickhull with
 outside sets, Barber et al. 1996) and the documented behaviour of its routines named in the comments below:
 initial simplex from the coordinate extremes, first partition, farthest-point insertion in facet-list order.
-Facet merging (nearly collinear hull points) is not restated; ``sure`` is False when a decision fell inside
-Qhull's roundoff bands, where merging could have changed the outcome.
+Of Qhull's facet merging only the outcome for points exactly in line on a hull edge is restated (the vertices
+between them go, and the merged facet stands in the list where its newest part stood); ``sure`` is False when
+a decision fell inside Qhull's roundoff bands, where merging could have changed more than that.
 
 Parity status: pinned by tests/golden/qhull_order.npz and the ``qhull*`` entries of hull_hybrid.npz and
 long_slices.npz - vertex lists scipy returned in the build container (tests/golden/gen_golden.py).
@@ -364,20 +365,47 @@ def vertices(xy):
         for f in new:
             f.new = False
     # scipy's walk: from the head facet, each facet's first vertex in its orientation, on to the neighbour
-    # opposite that vertex
-    order, f = [], flist[0]
+    # opposite that vertex.  Facets in one line (points exactly on a hull edge) are one facet in Qhull's result,
+    # which merged them: the vertex between two facets is left out when the far end of the second lies on the
+    # line of the first (Qhull's centrum test for two edges), and the merged facet stands in the list where its
+    # newest part stands.
+    walk, f = [], flist[0]
     for _ in range(len(flist) - 1):
-        order.append(f.v[0] if f.top else f.v[1])
+        walk.append(f)
         f = f.nb[0] if f.top else f.nb[1]
         if f is flist[0]:
             break
+    m = len(walk)
+
+    def in_line(i):                     # is the vertex between walk[i - 1] and walk[i] on one line with both?
+        f = walk[i]
+        return abs(dist(f.v[1] if f.top else f.v[0], walk[i - 1])) <= 4 * distround
+
+    joined = [in_line(i) for i in range(m)]
+    if all(joined) or m - sum(joined) < 3:
+        joined = [False] * m            # (no area left: nothing sensible to merge)
+    # runs of facets in one line, as (first facet's index in the walk, place in the list); a merged facet was
+    # appended to the list when its newest part was made, so it stands where that part stands
+    place = {id(f): k for k, f in enumerate(flist[:-1])}
+    first = next(i for i in range(m) if not joined[i])
+    runs, i = [], first
+    for _ in range(m):
+        if not joined[i]:
+            runs.append([i, place[id(walk[i])]])
+        else:
+            runs[-1][1] = max(runs[-1][1], place[id(walk[i])])
+        i = (i + 1) % m
+    head = min(range(len(runs)), key=lambda k: runs[k][1])
+    runs = runs[head:] + runs[:head]
+    order = [walk[i].v[0] if walk[i].top else walk[i].v[1] for i, _ in runs]
     return np.array(order, dtype=np.int64), sure[0]
 
 
 # --------------------------------------------------------------------------
 # inputs of the qhull_order fixtures (tests/golden/gen_golden.py records scipy's answer for them)
 # --------------------------------------------------------------------------
-KINDS = ("ring", "disk", "gauss", "grid", "far", "tiny", "square", "ellipse", "ringf32", "small", "arc", "slab")
+KINDS = ("ring", "disk", "gauss", "grid", "far", "tiny", "square", "ellipse", "ringf32", "small", "arc", "slab",
+         "rounded", "lattice")
 
 
 def make_case(kind, n, seed):
@@ -418,6 +446,11 @@ def make_case(kind, n, seed):
         bad = g.random(n) < 0.3
         r[bad] = g.uniform(0, 14.0, int(bad.sum()))
         xy = np.stack([3 + r * np.cos(th), -2 + r * np.sin(th)], 1)
+    elif kind == "rounded":         # a ring as a text file with few decimals holds it: points exactly in line
+        r = 10 + g.normal(0, 0.005, n)
+        xy = np.round(np.stack([3 + r * np.cos(th), -2 + r * np.sin(th)], 1), int(g.integers(0, 4)))
+    elif kind == "lattice":         # a handful of points on a small integer lattice
+        xy = g.integers(0, int(g.choice([4, 6, 9, 15])), (int(g.integers(4, 14)), 2)).astype(float)
     else:
         raise ValueError(kind)
     return np.unique(xy, axis=0)

@@ -40,7 +40,7 @@ class Replay {
     bool sure() const { return sure_; }
     int64_t count() const { return n_facets_; }
     // the vertices in scipy's order: from the head facet, each facet's first vertex in its orientation
-    void walk(int64_t *out, int64_t cap, int64_t *first) const;
+    void walk(int64_t *out, int64_t cap, int64_t *first);
 
   private:
     const double *x_, *y_;
@@ -459,16 +459,48 @@ bool Replay::run()
     return true;
 }
 
-void Replay::walk(int64_t *out, int64_t cap, int64_t *first) const
+void Replay::walk(int64_t *out, int64_t cap, int64_t *first)
 {
+    // the facets from the head of the list on, each giving its first vertex in its orientation
+    std::vector<int> w;
     int f = head_;
     for (int64_t i = 0; i < n_facets_; i++) {
-        const Facet &a = f_[f];
-        const int va = a.top ? a.v[0] : a.v[1];
-        if (i == 0 && first) *first = va;
-        if (out && i < cap) out[i] = va;
-        f = a.top ? a.nb[0] : a.nb[1];
+        w.push_back(f);
+        f = f_[f].top ? f_[f].nb[0] : f_[f].nb[1];
         if (f == head_) break;
+    }
+    const size_t m = w.size();
+    // Facets in one line (points exactly on a hull edge) are one facet in Qhull's result, which merged them: the
+    // vertex between two facets is left out when the far end of the second lies on the line of the first (Qhull's
+    // centrum test for two edges: half that distance against twice the roundoff of a distance), and the merged
+    // facet stands in the list where its newest part stands (it was appended when that part was made).
+    std::vector<char> joined(m, 0);
+    size_t n_joined = 0;
+    for (size_t i = 0; i < m; i++) {
+        const Facet &b = f_[w[i]];
+        joined[i] = std::fabs(dist(b.top ? b.v[1] : b.v[0], w[(i + m - 1) % m])) <= 4 * distround_;
+        n_joined += joined[i];
+    }
+    if (m - n_joined < 3) std::fill(joined.begin(), joined.end(), 0);          // (no area left: nothing to merge)
+    std::vector<int64_t> place(f_.size(), 0);
+    int64_t k = 0;
+    for (int g = head_; g != 0; g = f_[g].next) place[(size_t)g] = k++;
+    size_t start = 0;
+    while (joined[start]) start++;
+    std::vector<std::pair<size_t, int64_t>> runs;                              // (first facet in the walk, place in the list)
+    for (size_t t = 0, i = start; t < m; t++, i = (i + 1) % m) {
+        if (!joined[i]) runs.push_back({i, place[(size_t)w[i]]});
+        else runs.back().second = std::max(runs.back().second, place[(size_t)w[i]]);
+    }
+    size_t head = 0;
+    for (size_t r = 1; r < runs.size(); r++)
+        if (runs[r].second < runs[head].second) head = r;
+    n_facets_ = (int64_t)runs.size();
+    for (size_t t = 0; t < runs.size(); t++) {
+        const Facet &a = f_[w[runs[(head + t) % runs.size()].first]];
+        const int va = a.top ? a.v[0] : a.v[1];
+        if (t == 0 && first) *first = va;
+        if (out && (int64_t)t < cap) out[t] = va;
     }
 }
 

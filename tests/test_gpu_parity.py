@@ -173,7 +173,7 @@ def test_hybrid_in_qhulls_order_is_the_reference_without_hints():
 
 
 def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay():
-    """pcfit_qhull_start_batch_dev (one workgroup per slice) on the 720 recorded slices: where it answers, the
+    """pcfit_qhull_start_batch_dev (one workgroup per slice) on the 840 recorded slices: where it answers, the
     vertex is the one scipy listed first (tests/golden/qhull_order.npz); it answers on every slice of the kinds
     in general position, and hands back only slices the host replay is not sure of either, or sure and right."""
     import ctypes as C
@@ -205,11 +205,13 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
     assert np.array_equal(got[~deferred], g["first"][~deferred])
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
     assert int(why[:14].sum()) == int(deferred.sum())          # ([14], [15]: insertions and point visits)
-    # handed back: decisions near a threshold (integer grids, points on a square's edge, clusters far from the
-    # origin) and ties; on rings, disks, clouds, flat ellipses, arcs and the cylinder's slabs the kernel answers itself
+    # handed back: ties, points a few roundoff units above a facet, hulls with points exactly in line on an edge
+    # (integer grids, rounded coordinates); on rings, disks, clouds, flat ellipses, arcs and the cylinder's slabs the
+    # kernel answers itself
     plain = np.array([c[0] in ("ring", "disk", "gauss", "ringf32", "slab", "ellipse", "arc", "small") for c in cases])
     assert plain.sum() > 400 and deferred[plain].mean() < 0.01, (deferred[plain].mean(), why.tolist())
-    assert why[3] + why[4] + why[5] + why[9] + why[10] == deferred.sum(), why.tolist()
+    # (causes: ties for the farthest point, points a few roundoff units above a new facet, merged hull edges)
+    assert why[4] + why[10] + why[12] == deferred.sum(), why.tolist()
     # the library's own route (device first, host for what it hands back) equals the host replay everywhere
     h = F.unique_hull_batch(x, y, off, hull_start="qhull")
     for s_ in range(S):
