@@ -366,9 +366,8 @@ def vertices(xy):
             f.new = False
     # scipy's walk: from the head facet, each facet's first vertex in its orientation, on to the neighbour
     # opposite that vertex.  Facets in one line (points exactly on a hull edge) are one facet in Qhull's result,
-    # which merged them: the vertex between two facets is left out when the far end of the second lies on the
-    # line of the first (Qhull's centrum test for two edges), and the merged facet stands in the list where its
-    # newest part stands.
+    # which merged them: the vertex between two facets is left out when the centrum of one lies on the line of
+    # the other (Qhull's test), and the merged facet stands in the list where its newest part stands.
     walk, f = [], flist[0]
     for _ in range(len(flist) - 1):
         walk.append(f)
@@ -377,9 +376,17 @@ def vertices(xy):
             break
     m = len(walk)
 
-    def in_line(i):                     # is the vertex between walk[i - 1] and walk[i] on one line with both?
-        f = walk[i]
-        return abs(dist(f.v[1] if f.top else f.v[0], walk[i - 1])) <= 4 * distround
+    def centrum_dist(a, b):             # a's centrum (the mean of its vertices, brought onto its own line) from b's line
+        cx = (pts[a.v[0]][0] + pts[a.v[1]][0]) / 2
+        cy = (pts[a.v[0]][1] + pts[a.v[1]][1]) / 2
+        own = a.off + cx * a.n[0] + cy * a.n[1]
+        cx -= own * a.n[0]
+        cy -= own * a.n[1]
+        return b.off + cx * b.n[0] + cy * b.n[1]
+
+    def in_line(i):                     # Qhull's test of two facets: a centrum within the centrum radius of the other's line
+        radius = 2 * distround
+        return abs(centrum_dist(walk[i], walk[i - 1])) <= radius or abs(centrum_dist(walk[i - 1], walk[i])) <= radius
 
     joined = [in_line(i) for i in range(m)]
     if all(joined) or m - sum(joined) < 3:

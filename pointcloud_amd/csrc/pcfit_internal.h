@@ -22,12 +22,13 @@ int unique_hull_dev(const double *x, const double *y, const int64_t *offsets, in
 size_t unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices, int hull_only);
 // qhull_order.hip: the vertex Qhull's facet list starts with, per slice of sorted distinct points (host cores; only
 // where select is null or select[s] == PCFIT_HULL_START_QHULL, -1 elsewhere), and the turn of device walks
-// to the vertices with given coordinates (where found[s] >= 0; tmp: as many entries as hull_idx)
+// to the vertices with given coordinates and their reduction to Qhull's vertex set (where found[s] >= 0; n_hull is
+// updated; tmp: as many entries as hull_idx)
 int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk);
 int hull_order_mode();         // pcfit_set_hull_order's value
-int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const double *ux, const double *uy,
+int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, const double *uy,
                     const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
                     hipStream_t st);
 // qhull_dev.hip: the same replay on the device, one workgroup per slice, of slices that are sorted and distinct

@@ -550,7 +550,7 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
 static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
                               const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total, const double *px,
                               const double *py, const double *dux, const double *duy, const int64_t *doff,
-                              const int64_t *dnh, int64_t *dhi, hipStream_t st)
+                              int64_t *dnh, int64_t *dhi, hipStream_t st)
 {
     bool any = false;
     for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
@@ -832,6 +832,11 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
         PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu, S, total, dux.as<double>(),
                                      duy.as<double>(), dux.as<double>(), duy.as<double>(), doffp, dnh,
                                      dhi.as<int64_t>(), st));
+    if (use_hull && (qhull_raw || hull_start)) {
+        // (walks in Qhull's order are brought to Qhull's vertex set too: the counts may have gone down)
+        PCFIT_HIP(hipMemcpyAsync(n_hull.data(), dnh, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+    }
 
     // 2. candidates: hull vertices (circle_fitting.py:191-192) or all distinct points (:196-198)
     int64_t max_cand = 0;

@@ -717,11 +717,56 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     if (tid == 0) {
         int64_t out = QHULL_DEFER;
         if (S.state == 1) {
-            int count = 0;
-            for (int f = S.head; f != 0 && count <= QF; f = S.next[f]) count++;
-            // the strict hull the other kernel found has as many vertices, or something was merged or missed
-            if (count == n_hull[s]) out = S.top[S.head] ? S.v0[S.head] : S.v1[S.head];
-            else S.reason = 12;
+            // scipy's walk from the head of the list; facets in one line are one facet in Qhull's result (it merged
+            // them), standing in the list where the newest part stands.  (The free list, the visit marks and the
+            // visibility flags are idle by now and hold the walk, the places in the list and the joints.)
+            short *walk = S.free_slot;
+            unsigned short *place = S.visit;
+            unsigned char *joined = S.visible;
+            int m = 0, k = 0;
+            for (int f = S.head; m < QF;) {
+                walk[m++] = (short)f;
+                f = S.top[f] ? S.nb0[f] : S.nb1[f];
+                if (f == S.head) break;
+            }
+            for (int g = S.head; g != 0 && k < QF; g = S.next[g]) place[g] = (unsigned short)k++;
+            const double radius = 2 * S.thr[0];
+            int n_joined = 0;
+            auto centrum_dist = [&](int of, int to) {          // a facet's centrum, brought onto its own line, from another's line
+                double cx = (x[S.v0[of]] + x[S.v1[of]]) / 2, cy = (y[S.v0[of]] + y[S.v1[of]]) / 2;
+                const double own = plane_dist(S, of, cx, cy);
+                cx -= own * S.n0[of];
+                cy -= own * S.n1[of];
+                return plane_dist(S, to, cx, cy);
+            };
+            for (int i = 0; i < m; i++) {
+                const int b = walk[i], a = walk[(i + m - 1) % m];
+                joined[i] = fabs(centrum_dist(b, a)) <= radius || fabs(centrum_dist(a, b)) <= radius;
+                n_joined += joined[i];
+            }
+            if (m - n_joined < 3) {
+                for (int i = 0; i < m; i++) joined[i] = 0;
+                n_joined = 0;
+            }
+            int first = 0;
+            while (joined[first]) first++;
+            int count = 0, run_first = first, run_place = 0, best_first = first, best_place = 0x7fffffff;
+            for (int t = 0, i = first; t <= m; t++, i = (i + 1) % m) {
+                if (t == m || !joined[i]) {
+                    if (t > 0 && run_place < best_place) { best_place = run_place; best_first = run_first; }
+                    if (t == m) break;
+                    count++;
+                    run_first = i;
+                    run_place = place[walk[i]];
+                } else if ((int)place[walk[i]] > run_place)
+                    run_place = place[walk[i]];
+            }
+            // the strict hull the other kernel found has as many vertices, or more was merged than facets in line
+            if (m == k && count == n_hull[s]) {
+                const int h = walk[best_first];
+                out = S.top[h] ? S.v0[h] : S.v1[h];
+            } else
+                S.reason = 12;
         } else if (S.state == 0)
             S.reason = 13;
         if (out == QHULL_DEFER) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);

@@ -476,9 +476,20 @@ void Replay::walk(int64_t *out, int64_t cap, int64_t *first)
     // facet stands in the list where its newest part stands (it was appended when that part was made).
     std::vector<char> joined(m, 0);
     size_t n_joined = 0;
+    // (Qhull's test as it makes it: each facet's centrum - the mean of its vertices, brought onto its own line -
+    // against the other facet's line, within the centrum radius of twice the roundoff of a distance)
+    auto centrum_dist = [&](int of, int to) {
+        const Facet &a = f_[of], &b = f_[to];
+        double cx = (x_[a.v[0]] + x_[a.v[1]]) / 2, cy = (y_[a.v[0]] + y_[a.v[1]]) / 2;
+        const double own = a.off + cx * a.n0 + cy * a.n1;
+        cx -= own * a.n0;
+        cy -= own * a.n1;
+        return b.off + cx * b.n0 + cy * b.n1;
+    };
     for (size_t i = 0; i < m; i++) {
-        const Facet &b = f_[w[i]];
-        joined[i] = std::fabs(dist(b.top ? b.v[1] : b.v[0], w[(i + m - 1) % m])) <= 4 * distround_;
+        const int fa = w[(i + m - 1) % m], fb = w[i];
+        const double d1 = centrum_dist(fb, fa), d2 = centrum_dist(fa, fb), radius = 2 * distround_;
+        joined[i] = (d1 >= -radius && d1 <= radius) || (d2 >= -radius && d2 <= radius);
         n_joined += joined[i];
     }
     if (m - n_joined < 3) std::fill(joined.begin(), joined.end(), 0);          // (no area left: nothing to merge)
@@ -504,35 +515,84 @@ void Replay::walk(int64_t *out, int64_t cap, int64_t *first)
     }
 }
 
-// a device array of walks turned to start at the vertex with the given coordinates (no change where found[s] is
-// not 1 or no vertex has them)
-__global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restrict__ offsets,
-                                                          const int64_t *__restrict__ n_hull,
+// A device array of walks turned to start at the vertex with the given coordinates (no change where found[s] < 0
+// or no vertex has them), and brought to Qhull's vertex set: the walks come from an exact predicate and keep a
+// vertex at the slightest turn, Qhull merges two edges whose far end lies within its roundoff of the other's
+// line (coordinates rounded to a few decimals make such vertices), so a vertex goes when the centrum of the edge
+// before or after it lies within the centrum radius of the other's line - the rule the replay applies to its
+// own facets.  n_hull[s] becomes the number of vertices left.
+__global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restrict__ offsets, int64_t *__restrict__ n_hull,
                                                           const double *__restrict__ ux, const double *__restrict__ uy,
                                                           const int64_t *__restrict__ found,
                                                           const double *__restrict__ start_xy,
                                                           int64_t *__restrict__ hull_idx, int64_t *__restrict__ tmp)
 {
-    __shared__ int found_at;
+    __shared__ int found_at, any_joined;
+    __shared__ unsigned long long max_ax, max_ay;
     const int64_t s = blockIdx.x, off = offsets[s], h = n_hull[s];
     if (found[s] < 0 || h <= 0)
         return;
     const double sx = start_xy[2 * s], sy = start_xy[2 * s + 1];
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         found_at = 0x7fffffff;
+        any_joined = 0;
+        max_ax = max_ay = 0ull;
+    }
     __syncthreads();
     for (int64_t i = threadIdx.x; i < h; i += 256) {
         const int64_t v = hull_idx[off + i];
         tmp[off + i] = v;
         if (ux[off + v] == sx && uy[off + v] == sy)
             atomicMin(&found_at, (int)i);
+        // (the largest coordinates of a slice are those of hull vertices; non-negative doubles order like their bits)
+        atomicMax(&max_ax, (unsigned long long)__double_as_longlong(fabs(ux[off + v])));
+        atomicMax(&max_ay, (unsigned long long)__double_as_longlong(fabs(uy[off + v])));
     }
     __syncthreads();
-    const int p0 = found_at;
-    if (p0 == 0x7fffffff || p0 == 0)
+    const int64_t p0 = found_at == 0x7fffffff ? 0 : found_at;
+    const double ax = __longlong_as_double((long long)max_ax), ay = __longlong_as_double((long long)max_ay);
+    const double maxabs = fmax(ax, ay);
+    const double distround = 2.220446049250313e-16 * (2 * fmin(sqrt(2.0) * maxabs, ax + ay) * 1.01 + maxabs);
+    auto vertex = [&](int64_t i) { return tmp[off + (i + p0 + h) % h]; };          // the walk from the start vertex
+    // does vertex i of that walk go?  Qhull's test of the edges before and after it: the centrum of one (the mean of
+    // its ends, brought onto its own line) within the centrum radius - twice the roundoff - of the other's line
+    auto joined = [&](int64_t i) {
+        const int64_t a = vertex(i - 1), b = vertex(i), c = vertex(i + 1);
+        const double px[3] = {ux[off + a], ux[off + b], ux[off + c]}, py[3] = {uy[off + a], uy[off + b], uy[off + c]};
+        double n0[2], n1[2], o[2];
+        for (int e = 0; e < 2; e++) {
+            const double nx = py[e + 1] - py[e], ny = px[e] - px[e + 1], norm = sqrt(nx * nx + ny * ny);
+            n0[e] = nx / norm;
+            n1[e] = ny / norm;
+            o[e] = -(px[e] * n0[e] + py[e] * n1[e]);
+        }
+        bool in_line = false;
+        for (int e = 0; e < 2; e++) {
+            double cx = (px[e] + px[e + 1]) / 2, cy = (py[e] + py[e + 1]) / 2;
+            const double own = o[e] + cx * n0[e] + cy * n1[e];
+            cx -= own * n0[e];
+            cy -= own * n1[e];
+            const double d = o[1 - e] + cx * n0[1 - e] + cy * n1[1 - e];
+            in_line = in_line || fabs(d) <= 2 * distround;
+        }
+        return in_line;
+    };
+    for (int64_t i = threadIdx.x; i < h; i += 256) {
+        hull_idx[off + i] = vertex(i);
+        if (i > 0 && h > 3 && joined(i)) any_joined = 1;
+    }
+    __syncthreads();
+    if (!any_joined || threadIdx.x != 0)
         return;
-    for (int64_t i = threadIdx.x; i < h; i += 256)
-        hull_idx[off + i] = tmp[off + (i + p0) % h];
+    // rare: one thread closes the gaps, in order (the start vertex stays whatever its angle)
+    int64_t n_joined = 0;
+    for (int64_t i = 1; i < h; i++) n_joined += joined(i);
+    if (h - n_joined < 3)
+        return;
+    int64_t kept = 1;
+    for (int64_t i = 1; i < h; i++)
+        if (!joined(i)) hull_idx[off + kept++] = vertex(i);
+    n_hull[s] = kept;
 }
 
 }  // namespace
@@ -573,7 +633,7 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
     return PCFIT_OK;
 }
 
-int hull_rotate_dev(const int64_t *offsets, const int64_t *n_hull, const double *ux, const double *uy,
+int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, const double *uy,
                     const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
                     hipStream_t st)
 {

@@ -49,7 +49,7 @@ def main(rounds=20, seed=0):
                 continue
             walk = h["hull_idx"][off[s]:off[s] + nh]
             hw = host["walk"][off[s]:off[s] + host["n_walk"][s]]
-            same = walk[0] == host["start"][s] and (not host["sure"][s] or np.array_equal(walk, hw))
+            same = np.array_equal(walk, hw)          # start and vertex set: Qhull's, merged vertices left out
             if not same and not host["sure"][s]:
                 open_ += 1          # points exactly in line: the host replay's answer is a best effort itself
                 if os.path.isdir("gpurun_out"):

@@ -218,6 +218,9 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
         nh = int(h["n_hull"][s_])
         if nh >= 3 and host["start"][s_] >= 0:
             assert h["hull_idx"][off[s_]] == host["start"][s_], (s_, cases[s_][0])
+        # ... and the whole walk is the list scipy returned, the vertices Qhull merged away left out (rounded
+        # coordinates, lattices: the exact predicate of the hull kernel keeps them, the walk in Qhull's order does not)
+        assert nh == int(g["count"][s_]) and _sha(h["hull_idx"][off[s_]:off[s_] + nh]) == str(g["sha"][s_]), (s_, cases[s_][0])
     # a hull of more vertices than the kernel has facet slots (every point of a circle): the host replay takes it
     th = np.linspace(0.0, 2 * np.pi, 3000, endpoint=False)
     circ = np.unique(np.stack([5 * np.cos(th) + 0.25, 5 * np.sin(th) - 1.5], 1), axis=0)
