@@ -296,7 +296,7 @@ def hybrid_fit(points_xyz, z_elevation, z_tolerance, inlier_tol=0.5, max_trials=
             from . import qhull2d
             order, _ = qhull2d.vertices(xy)
             if order is not None:
-                verts = rotate_to(verts, order[0])
+                verts = order                   # Qhull's own list: its tolerance may leave out a vertex of the exact hull
         elif hull_start is not None:
             verts = rotate_to(verts, hull_start)
         if use_hull_vertices_only and verts.size >= 3:
@@ -440,7 +440,7 @@ def residual_profile_at_z(points_xyz, res_fit, z_elevation, z_tolerance, use_hul
             from . import qhull2d
             order, _ = qhull2d.vertices(xy)
             if order is not None:
-                verts = rotate_to(verts, order[0])
+                verts = order                   # Qhull's own list: its tolerance may leave out a vertex of the exact hull
         elif hull_start is not None:
             verts = rotate_to(verts, hull_start)
         if verts.size >= 3:

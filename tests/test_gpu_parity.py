@@ -164,6 +164,17 @@ def test_hybrid_in_qhulls_order_is_the_reference_without_hints():
         if bool(g[f"ok{i}"]):
             assert np.array_equal(np.stack([hy_named["cand_x"][c0:c1], hy_named["cand_y"][c0:c1]], 1), g[f"cand{i}"])
             assert np.array_equal(hy_named["mask"][c0:c1], g[f"mask{i}"])
+    # coordinates as a text file with two or three decimals holds them: points exactly in line on hull edges, which
+    # Qhull merges away (the restatement's list is pinned to scipy's on such slices in test_qhull_order.py)
+    from oracle import qhull2d as Q
+    for seed in range(12):
+        xy = Q.make_case("rounded", 3000, 900 + seed)
+        pts3 = np.column_stack([xy, np.zeros(len(xy))])
+        res = CF.fit_circle_hybrid_at_z(pts3, 0.0, 0.5, max_trials=200)
+        ref = R.hybrid_fit(pts3, 0.0, 0.5, max_trials=200, hull_start="qhull")
+        assert np.array_equal(res["candidates_xy"], ref["candidates_xy"]), seed
+        assert np.array_equal(res["inlier_mask"], ref["inlier_mask"]), seed
+        assert rel([res["center_x"], res["center_y"], res["radius"]], [ref["center_x"], ref["center_y"], ref["radius"]]) < 1e-9
     g = load_golden("long_slices")
     for i, (n, seed, outlier, dup) in enumerate(g["cases"]):
         pts = R.make_slab(int(n), int(seed), float(outlier), int(dup))
