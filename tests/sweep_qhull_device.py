@@ -78,6 +78,8 @@ def main(rounds=20, seed=0):
         slices += len(off) - 1
         points += int(off[-1])
         handed += int(why[:14].sum())
+        if (r + 1) % 10 == 0:
+            print(f"round {r + 1}/{rounds}: {slices + len(off) - 1} slices, {bad} differences", flush=True)
     print(f"{rounds} rounds, {slices} slices, {points} points, {time.time() - t0:.0f} s: {bad} differences "
           f"(and {open_} on slices the host replay is not sure of); {quant} slices with rounded coordinates; "
           f"handed back to the host {handed} ({why_all[:14].tolist()})")
