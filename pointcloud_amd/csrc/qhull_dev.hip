@@ -8,8 +8,8 @@
 // search by the one thread afterwards (whatever mode Qhull's search is in by then, it ends in that walk).  Where
 // the order inside a set would matter - two points tie for the farthest of a set, a point lies 4 to 8 roundoff
 // units above the first new facet, two facets get their first point through the horizon search in one
-// insertion - or one of the fixed capacities below runs out, or the replay ends with another number of vertices
-// than the strict hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
+// insertion - or one of the fixed capacities below runs out, or the replay ends with more vertices than
+// the exact hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
 #include "pcfit_internal.h"
 
 namespace pcfit {
@@ -761,8 +761,10 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 } else if ((int)place[walk[i]] > run_place)
                     run_place = place[walk[i]];
             }
-            // the strict hull the other kernel found has as many vertices, or more was merged than facets in line
-            if (m == k && count == n_hull[s]) {
+            // the hull the other kernel found by an exact predicate has these vertices and, where coordinates were
+            // rounded, some at the slightest of turns that Qhull does not keep (the turn of the walk takes them out);
+            // fewer there than here would mean that something was missed
+            if (m == k && count <= n_hull[s]) {
                 const int h = walk[best_first];
                 out = S.top[h] ? S.v0[h] : S.v1[h];
             } else
