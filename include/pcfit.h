@@ -20,7 +20,11 @@
  *    from the caller (pcfit_*_workspace_bytes tells how much).
  *  - Entry points without "_dev" take HOST pointers (numpy buffers): they
  *    allocate device memory, copy in, run the same kernels, copy out,
- *    synchronise and free.  They are re-entrant; no global mutable state.
+ *    synchronise and free.  They are re-entrant: a call's results depend on its
+ *    arguments only.  What the library keeps between calls is invisible in the
+ *    results - the per-device cache of device blocks and the cache of RANSAC
+ *    sampling tables (both mutex-guarded), the last-error text of each thread,
+ *    and two counters for tools (pcfit_debug_qhull_reasons).
  *  - Per-slice status codes (int32): 0 ok, 1 too few points, 2 no 2-D
  *    variation (rank deficient), 3 RANSAC consensus below the minimum,
  *    4 singular system.
@@ -264,8 +268,25 @@ int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *o
  * than 3 points. */
 /* In the host-pointer forms below (pcfit_unique_hull_batch, pcfit_hybrid_batch) a hull_start entry of
  * PCFIT_HULL_START_QHULL asks for the vertex scipy.spatial.ConvexHull(xy).vertices lists first
- * (circle_fitting.py:189-190), found by pcfit_qhull_order_batch on the host. */
+ * (circle_fitting.py:189-190), found by a replay of Qhull's construction on the device
+ * (pcfit_qhull_start_batch_dev; the few slices that kernel hands back are replayed on host cores as in
+ * pcfit_qhull_order_batch); the walk is then also reduced to Qhull's vertex set (a vertex between two
+ * hull edges that Qhull merges - points exactly in line - is left out, n_hull goes down). */
 #define PCFIT_HULL_START_QHULL (-2)
+
+/* The order of the hull candidates of a whole call (the hull_order argument of pcfit_hybrid_batch and of the
+ * scan forms).  RANSAC samples candidates by index (circle_fitting.py:126 on :191-192's array), so the order
+ * decides which triples are drawn and, on slices with outliers on the hull, the inlier set and the fit.
+ *   PCFIT_HULL_ORDER_QHULL      the order of circle_fitting.py:189-192's xy[hull.vertices], element for
+ *                               element: candidates, inlier mask and fit are the reference's.  This is what
+ *                               the Python layers of this package pass unless told otherwise.
+ *   PCFIT_HULL_ORDER_CANONICAL  counter-clockwise from the lexicographically smallest vertex, every vertex
+ *                               of the exact hull kept: no replay of Qhull (about a third faster on a
+ *                               100 M-point scan); same vertex set and cyclic order, other sampled triples.
+ * There is no default and no process-wide setting: every call states its order, so calls from several
+ * threads (analyzer.py:203-207 enters the numerics from a thread pool) cannot change each other's results. */
+#define PCFIT_HULL_ORDER_CANONICAL 0
+#define PCFIT_HULL_ORDER_QHULL 1
 size_t pcfit_unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices);
 int pcfit_unique_hull_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                 int64_t max_slice_len, double *ux, double *uy, int64_t *n_unique,
@@ -327,8 +348,11 @@ int pcfit_ovality_batch(const double *x, const double *y, const int64_t *offsets
  * slices of distinct points laid out like the ux / uy / n_unique of pcfit_unique_hull_batch (n_unique NULL:
  * every slice is full).  start[s]: index of the first vertex in the slice's array, -1 when there is no hull.
  * Nullable: sure[s] = 0 when a decision fell inside Qhull's roundoff bands (nearly collinear hull points,
- * points on an edge of the hull: Qhull would merge facets there, which is not replayed) and start[s] is a
- * best effort; walk (capacity as ux) + n_walk[s]: all vertices in scipy's order.  No GPU work. */
+ * points on an edge of the hull).  Of Qhull's facet merging the replay performs the one case such data
+ * needs - two facets of which one's centrum lies within the centrum radius of the other's line become one
+ * facet, the vertex between them goes - and nothing else, so sure[s] = 0 marks slices on which more of the
+ * merging could have played a part (none of those tried differed from scipy's list), not slices known to
+ * differ; walk (capacity as ux) + n_walk[s]: all vertices in scipy's order.  No GPU work. */
 int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                             int64_t n_slices, int32_t n_threads, int64_t *start, uint8_t *sure, int64_t *walk,
                             int64_t *n_walk);
@@ -352,14 +376,6 @@ int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_
  * first partition).  For tools and tests; synchronises the device. */
 int pcfit_debug_qhull_reasons(int64_t *out16, int reset);
 
-/* Where the hull walks of the hybrid chain start when the caller names no hull_start (and in the scan forms,
- * which take none): 0 (default) = at the lexicographic minimum, 1 = where scipy's ConvexHull starts, as
- * pcfit_qhull_order_batch finds it - the candidates then are circle_fitting.py:189-192's `xy[hull.vertices]`
- * element for element, at the price of bringing the distinct points of every slice back to the host and one
- * pass of the host cores over them.  A setting of the process, read at the start of a call. */
-int pcfit_set_hull_order(int32_t order);
-int pcfit_get_hull_order(int32_t *order);
-
 /* _has_enough_2d_variation (circle_fitting.py:14-19) per slice: ok[s] = 1 when
  * the second singular value of the centred points exceeds eps*(first + eps). */
 int pcfit_rank_check_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices, double eps,
@@ -373,9 +389,11 @@ int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, u
  * are already cut to their z window, followed by the per-slice metrics of
  * CylinderAnalyzer.process_slice (analyzer.py:83-95).  Host pointers.
  * In: r_range NULL or 2 doubles; use_hull = use_hull_vertices_only;
- *     hull_start NULL or S entries (-1 = walk the hull from its lexicographic
- *     minimum; otherwise the index, in the slice's unique array, of the vertex
- *     to start from - lets a caller replay Qhull's order).
+ *     hull_order PCFIT_HULL_ORDER_QHULL or PCFIT_HULL_ORDER_CANONICAL (above): the order of
+ *     every slice's hull candidates when hull_start is NULL;
+ *     hull_start NULL, or S entries that decide slice by slice instead of hull_order:
+ *     -1 = from the lexicographic minimum, PCFIT_HULL_START_QHULL = Qhull's order,
+ *     otherwise the index, in the slice's unique array, of the vertex to start from.
  * Out (capacity of every per-point array = offsets[S]):
  *     status S (0 ok / 1 / 2 / 3: the reference returns None), fit S*3,
  *     ux, uy + n_unique S        the sorted distinct points (fit_points_xy), all of them for
@@ -391,8 +409,8 @@ int pcfit_circle3_batch(const double *triples, int64_t n_triples, double *out, u
  *     ov_scal S*5, dev_uniform (nullable, rows grid_len apart)   ovality_and_fourier. */
 int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                        double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
-                       double huber_delta, int32_t use_hull, const int64_t *hull_start, uint64_t seed,
-                       int32_t *status, double *fit, double *ux, double *uy, int64_t *n_unique,
+                       double huber_delta, int32_t use_hull, const int64_t *hull_start, int32_t hull_order,
+                       uint64_t seed, int32_t *status, double *fit, double *ux, double *uy, int64_t *n_unique,
                        int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
                        double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
                        int64_t grid_len);
@@ -408,11 +426,11 @@ int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets,
  *     the outputs of pcfit_hybrid_batch without ux / uy; the candidate arrays
  *     (cand_x, cand_y, mask, radius, theta) hold cand_capacity entries and the
  *     call fails with PCFIT_ERR_INVALID, naming the count, when more are needed.
- * hull_start is not offered: every hull is walked from its lexicographic minimum. */
+ * hull_order as in pcfit_hybrid_batch (per-slice start vertices are not offered here). */
 int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
                             int64_t n_slices, double inlier_tol, int32_t max_trials, double min_inliers_frac,
-                            const double *r_range, double huber_delta, int32_t use_hull, uint64_t seed,
-                            int64_t *offsets, int32_t *status, double *fit, int64_t *n_unique,
+                            const double *r_range, double huber_delta, int32_t use_hull, int32_t hull_order,
+                            uint64_t seed, int64_t *offsets, int32_t *status, double *fit, int64_t *n_unique,
                             int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
                             double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
                             int64_t grid_len, int64_t cand_capacity);
@@ -457,8 +475,8 @@ int pcfit_scan_window_counts(const pcfit_scan *scan, const double *z_lo, const d
                              int64_t *counts);
 int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi, int64_t n_slices,
                                double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
-                               double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets,
-                               int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets,
+                               double huber_delta, int32_t use_hull, int32_t hull_order, uint64_t seed,
+                               int64_t *offsets, int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets,
                                double *cand_x, double *cand_y, uint8_t *mask, double *radius, double *theta,
                                int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
                                int64_t cand_capacity);

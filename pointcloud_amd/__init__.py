@@ -7,6 +7,6 @@ The modules mirror the reference's layout and call signatures
 (include/pcfit.h) to hand-written HIP kernels.  There is no CPU fallback.
 """
 from .analyzer import Config, CylinderAnalyzer  # noqa: F401
-from ._ffi import DeviceScan, get_hull_order, set_hull_order  # noqa: F401
+from ._ffi import DeviceScan  # noqa: F401
 
-__all__ = ["Config", "CylinderAnalyzer", "DeviceScan", "get_hull_order", "set_hull_order"]
+__all__ = ["Config", "CylinderAnalyzer", "DeviceScan"]

@@ -7,9 +7,7 @@ manage device memory themselves (bench.py does, through torch).
 """
 from __future__ import annotations
 
-import contextlib
 import ctypes as C
-import threading
 import os
 
 import numpy as np
@@ -93,11 +91,9 @@ SIGNATURES = {
     "pcfit_qhull_order_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
     "pcfit_qhull_start_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
     "pcfit_debug_qhull_reasons": (C.c_int, [_vp, C.c_int]),
-    "pcfit_set_hull_order": (C.c_int, [_i32]),
-    "pcfit_get_hull_order": (C.c_int, [_vp]),
     "pcfit_rank_check_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),
-    "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _u64] + [_vp] * 14
+    "pcfit_hybrid_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _vp, _i32, _u64] + [_vp] * 14
                            + [_i64]),
     "pcfit_count_text_lines": (C.c_int, [_vp, _sz, _i32, _vp]),
     "pcfit_format_csv_rows": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp, _sz, _vp]),
@@ -109,9 +105,9 @@ SIGNATURES = {
     "pcfit_scan_upload_z_range": (C.c_int, [_vp, _i64, _f64, _f64, C.POINTER(_vp), _vp]),
     "pcfit_scan_bin_slices": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp]),
     "pcfit_scan_window_counts": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
+    "pcfit_scan_hybrid_resident": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _i32, _u64]
                                    + [_vp] * 13 + [_i64, _i64]),
-    "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _u64]
+    "pcfit_scan_hybrid_batch": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _f64, _i32, _f64, _vp, _f64, _i32, _i32, _u64]
                                 + [_vp] * 13 + [_i64, _i64]),
 }
 
@@ -311,34 +307,16 @@ def qhull_order_batch(ux, uy, offsets=None, n_unique=None, n_threads=0, want_wal
     return dict(start=start, sure=sure.astype(bool), walk=walk, n_walk=n_walk, offsets=offsets)
 
 
-def set_hull_order(order):
-    """Where hull walks start when no hull_start is given: "canonical" (the lexicographic minimum, default)
-    or "qhull" (where scipy's ConvexHull starts; costs a host pass over every slice's distinct points)."""
-    check(lib().pcfit_set_hull_order({"canonical": 0, "qhull": 1}[order]))
+HULL_ORDERS = {"canonical": 0, "qhull": 1}      # PCFIT_HULL_ORDER_CANONICAL, PCFIT_HULL_ORDER_QHULL
 
 
-def get_hull_order():
-    v = np.zeros(1, np.int32)
-    check(lib().pcfit_get_hull_order(_p(v)))
-    return ("canonical", "qhull")[int(v[0])]
-
-
-_order_lock = threading.RLock()
-
-
-@contextlib.contextmanager
-def hull_order(order):
-    """The library's process-wide hull order for the calls made inside the block (None: leave it as it is)."""
-    if order is None:
-        yield
-        return
-    with _order_lock:
-        before = get_hull_order()
-        set_hull_order(order)
-        try:
-            yield
-        finally:
-            set_hull_order(before)
+def _hull_order(order) -> int:
+    """The hull_order argument of the C ABI for "qhull" (the order of scipy's ConvexHull(xy).vertices, which is
+    the reference's: the default of every Python layer) or "canonical" (from the lexicographic minimum)."""
+    try:
+        return HULL_ORDERS[order]
+    except (KeyError, TypeError):
+        raise ValueError('order: "qhull" or "canonical"') from None
 
 
 def unique_hull_batch(x, y, offsets=None, hull_start=None):
@@ -386,8 +364,11 @@ OV_CAP = 8192          # candidates per slice that the ovality kernel holds in L
 
 
 def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
-                 huber_delta=1.0, use_hull=True, hull_start=None, seed=42, want_profile=True, want_unique=True):
-    """fit_circle_hybrid_at_z + the metrics of process_slice for every slice of a CSR batch."""
+                 huber_delta=1.0, use_hull=True, hull_start=None, seed=42, want_profile=True, want_unique=True,
+                 order="qhull"):
+    """fit_circle_hybrid_at_z + the metrics of process_slice for every slice of a CSR batch.  ``order``: the
+    order of every slice's hull candidates, "qhull" (the reference's) or "canonical"; ``hull_start`` (per-slice
+    indices, -1 = lexicographic minimum, HULL_START_QHULL; or "qhull") decides slice by slice instead."""
     x, y, offsets = as_csr(x, y, offsets)
     S = offsets.size - 1
     tot = max(int(x.size), 1)
@@ -409,7 +390,8 @@ def hybrid_batch(x, y, offsets=None, inlier_tol=0.5, max_trials=4000, min_inlier
     rr = None if r_range is None else _arr(r_range, np.float64)
     hs = _hull_starts(hull_start, S)
     check(lib().pcfit_hybrid_batch(_p(x), _p(y), _p(offsets), S, inlier_tol, max_trials, min_inliers_frac, _p(rr),
-                                   huber_delta, 1 if use_hull else 0, _p(hs), int(seed), _p(status), _p(fit), _p(ux),
+                                   huber_delta, 1 if use_hull else 0, _p(hs), _hull_order(order), int(seed), _p(status),
+                                   _p(fit), _p(ux),
                                    _p(uy), _p(n_unique), _p(cand_off), _p(cx_), _p(cy_), _p(mask), _p(radius),
                                    _p(theta), _p(amm), _p(ov), _p(dev), K))
     nc = int(cand_off[-1])
@@ -491,10 +473,11 @@ def host_window_counts(points, z_lo, z_hi, n_threads: int = 0):
 
 
 def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_inliers_frac=0.1, r_range=None,
-                      huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None, order=None):
+                      huber_delta=1.0, use_hull=True, seed=42, want_profile=False, cand_capacity=None, order="qhull"):
     """bin_slices + hybrid_batch without the round trip of the binned points: the scan (an (N,3) array, uploaded
     for this call, or a DeviceScan already on the GPU) is binned on the device and only per-slice results and
-    candidates come back.  ``order``: "qhull" / "canonical" for this call (None: the process-wide setting).  With hull candidates the candidate arrays start small and the call is repeated once
+    candidates come back.  ``order``: "qhull" (the reference's candidate order) or "canonical", an
+    argument of this call alone.  With hull candidates the candidate arrays start small and the call is repeated once
     with the needed size if they were too small."""
     if isinstance(points, DeviceScan):
         if not points._handle:
@@ -513,6 +496,7 @@ def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_i
     if cand_capacity is None:
         cand_capacity = 2 * N if not use_hull else min(2 * N, max(1 << 20, 1024 * S))
     rr = None if r_range is None else _arr(r_range, np.float64)
+    order_code = _hull_order(order)
     K = OV_CAP
     while True:
         cap = max(int(cand_capacity), 1)
@@ -527,10 +511,9 @@ def scan_hybrid_batch(points, z_lo, z_hi, inlier_tol=0.5, max_trials=4000, min_i
         amm = np.zeros((S, 2), np.int64)
         ov = np.zeros((S, 5))
         dev = np.full((S, K), np.nan) if want_profile else None
-        with hull_order(order):
-            rc = head[0](*head[1], _p(z_lo), _p(z_hi), S, inlier_tol, max_trials, min_inliers_frac, _p(rr), huber_delta,
-                         1 if use_hull else 0, int(seed), _p(offsets), _p(status), _p(fit), _p(n_unique), _p(cand_off),
-                         _p(cx_), _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
+        rc = head[0](*head[1], _p(z_lo), _p(z_hi), S, inlier_tol, max_trials, min_inliers_frac, _p(rr), huber_delta,
+                     1 if use_hull else 0, order_code, int(seed), _p(offsets), _p(status), _p(fit), _p(n_unique),
+                     _p(cand_off), _p(cx_), _p(cy_), _p(mask), _p(radius), _p(theta), _p(amm), _p(ov), _p(dev), K, cap)
         if rc != 0 and int(cand_off[-1]) > cap:           # candidate arrays too small: the count is known now
             cand_capacity = int(cand_off[-1])
             continue

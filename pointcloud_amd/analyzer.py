@@ -111,8 +111,10 @@ class CylinderAnalyzer:
             points = np.asarray(points, float)
         if hull_start is None:
             hull_start = self.config.hull_order
-        hs = (np.array([-1], np.int64) if hull_start == "canonical" else hull_start if isinstance(hull_start, str)
-              else np.array([hull_start], np.int64))
+        if isinstance(hull_start, str):
+            hs, order = None, hull_start
+        else:
+            hs, order = np.array([hull_start], np.int64), "canonical"
         dz = self.config.z_step / 2.0
         offsets, x, y, _ = _ffi.bin_slices(points, np.array([z_center - dz]), np.array([z_center + dz]),
                                            want_perm=False)
@@ -120,7 +122,8 @@ class CylinderAnalyzer:
         if n0 < self.config.min_points_per_slice:
             return None, None, f"SKIP zc={z_center:.3f}: too sparse ({n0} points)"
         h = _ffi.hybrid_batch(x, y, offsets, _FIT["inlier_tol"], _FIT["max_trials"], _FIT["min_inliers_frac"], None,
-                              _FIT["huber_delta"], _FIT["use_hull"], hs, want_profile=True, want_unique=False)
+                              _FIT["huber_delta"], _FIT["use_hull"], hs, want_profile=True, want_unique=False,
+                              order=order)
         slc = np.stack([x, y], axis=1)
         if n0 > self.config.max_points_for_speed:
             # the reference thins only what it hands back for plotting; the fit sees every point

@@ -27,7 +27,6 @@ size_t unique_hull_workspace_bytes(int64_t total_points, int64_t n_slices, int h
 int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk);
-int hull_order_mode();         // pcfit_set_hull_order's value
 int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, const double *uy,
                     const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
                     hipStream_t st);

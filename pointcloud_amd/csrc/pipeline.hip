@@ -547,10 +547,10 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
 // duy, and the vertex is found there by its coordinates).  Slices the kernel hands back - decisions inside
 // Qhull's roundoff bands, ties, capacities - have their points brought to the host and are replayed there (all
 // selected slices with PCFIT_QHULL_ON_HOST=1 in the environment).
-static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
-                              const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total, const double *px,
-                              const double *py, const double *dux, const double *duy, const int64_t *doff,
-                              int64_t *dnh, int64_t *dhi, hipStream_t st)
+static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
+                                   const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total,
+                                   const double *px, const double *py, const double *dux, const double *duy,
+                                   const int64_t *doff, int64_t *dnh, int64_t *dhi, hipStream_t st)
 {
     bool any = false;
     for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
@@ -625,6 +625,22 @@ static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_s
     PCFIT_TRY(hull_rotate_dev(doff, dnh, dux, duy, dstart.as<int64_t>(), dxy.as<double>(), S, dhi, dtmp.as<int64_t>(), st));
     PCFIT_HIP(hipStreamSynchronize(st));               // start (pageable) and the buffers end with this call
     return PCFIT_OK;
+}
+
+// (host containers may run out of memory: that is an error code, not an exception through the C ABI)
+static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
+                              const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total, const double *px,
+                              const double *py, const double *dux, const double *duy, const int64_t *doff,
+                              int64_t *dnh, int64_t *dhi, hipStream_t st)
+{
+    try {
+        return apply_qhull_starts_impl(hull_start, d_hull_start, offsets, n_pts, d_n_pts, S, total, px, py, dux, duy,
+                                       doff, dnh, dhi, st);
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(st);                // nothing of this call may still be copying into freed vectors
+        set_error("qhull order: %s", e.what());
+        return PCFIT_ERR_INVALID;
+    }
 }
 
 // ------------------------------------------------- host-pointer entry points
@@ -777,14 +793,17 @@ static int sampling_tables(const uint64_t state[4], const std::vector<int64_t> &
 // The chain on slices that are already on the device (dxp, dyp, doffp; offsets = the same CSR offsets on
 // the host).  ux / uy may be null (then the distinct points stay on the device); the candidate arrays hold
 // cand_capacity entries.
-static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doffp, const int64_t *offsets, int64_t S,
-                       int64_t total, int64_t max_len, double inlier_tol, int32_t max_trials, double min_inliers_frac,
-                       const double *r_range, double huber_delta, int32_t use_hull, const int64_t *hull_start,
-                       uint64_t seed, int32_t *status, double *fit, double *ux, double *uy, int64_t *n_unique,
-                       int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask, double *radius,
-                       double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len,
-                       int64_t cand_capacity, hipStream_t st)
+static int hybrid_core_impl(const double *dxp, const double *dyp, const int64_t *doffp, const int64_t *offsets,
+                            int64_t S, int64_t total, int64_t max_len, double inlier_tol, int32_t max_trials,
+                            double min_inliers_frac, const double *r_range, double huber_delta, int32_t use_hull,
+                            const int64_t *hull_start, int32_t hull_order, uint64_t seed, int32_t *status, double *fit,
+                            double *ux, double *uy, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                            double *cand_y, uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin,
+                            double *ov_scal, double *dev_uniform, int64_t grid_len, int64_t cand_capacity,
+                            hipStream_t st)
 {
+    PCFIT_REQUIRE(hull_order == PCFIT_HULL_ORDER_CANONICAL || hull_order == PCFIT_HULL_ORDER_QHULL,
+                  "hybrid: hull_order must be PCFIT_HULL_ORDER_CANONICAL (0) or PCFIT_HULL_ORDER_QHULL (1)");
     // Small per-slice arrays travel packed, one copy per stage and direction: every copy from or to
     // pageable memory is a blocking call of some tens of microseconds, more than the kernels of a small scan.
     auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
@@ -796,7 +815,7 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     // reads the slices as they are
     std::vector<int64_t> qhull_everywhere;
     bool qhull_raw = false;
-    if (!hull_start && use_hull && hull_order_mode() == 1) {
+    if (!hull_start && use_hull && hull_order == PCFIT_HULL_ORDER_QHULL) {
         qhull_everywhere.assign((size_t)S, PCFIT_HULL_START_QHULL);
         if (!ux && !uy) qhull_raw = true;
         else hull_start = qhull_everywhere.data();
@@ -984,15 +1003,38 @@ static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doff
     return PCFIT_OK;
 }
 
+static int hybrid_core(const double *dxp, const double *dyp, const int64_t *doffp, const int64_t *offsets, int64_t S,
+                       int64_t total, int64_t max_len, double inlier_tol, int32_t max_trials, double min_inliers_frac,
+                       const double *r_range, double huber_delta, int32_t use_hull, const int64_t *hull_start,
+                       int32_t hull_order, uint64_t seed, int32_t *status, double *fit, double *ux, double *uy,
+                       int64_t *n_unique, int64_t *cand_offsets, double *cand_x, double *cand_y, uint8_t *mask,
+                       double *radius, double *theta, int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
+                       int64_t grid_len, int64_t cand_capacity, hipStream_t st)
+{
+    try {
+        return hybrid_core_impl(dxp, dyp, doffp, offsets, S, total, max_len, inlier_tol, max_trials, min_inliers_frac,
+                                r_range, huber_delta, use_hull, hull_start, hull_order, seed, status, fit, ux, uy,
+                                n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal,
+                                dev_uniform, grid_len, cand_capacity, st);
+    } catch (const std::exception &e) {
+        (void)hipStreamSynchronize(st);
+        set_error("hybrid: %s", e.what());
+        return PCFIT_ERR_INVALID;
+    }
+}
+
 PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                  double inlier_tol, int32_t max_trials, double min_inliers_frac,
                                  const double *r_range, double huber_delta, int32_t use_hull,
-                                 const int64_t *hull_start, uint64_t seed, int32_t *status, double *fit, double *ux,
+                                 const int64_t *hull_start, int32_t hull_order, uint64_t seed, int32_t *status,
+                                 double *fit, double *ux,
                                  double *uy, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
                                  double *cand_y, uint8_t *mask, double *radius, double *theta,
                                  int64_t *argmax_argmin, double *ov_scal, double *dev_uniform, int64_t grid_len)
 {
     PCFIT_ENTER();
+    PCFIT_REQUIRE(hull_order == PCFIT_HULL_ORDER_CANONICAL || hull_order == PCFIT_HULL_ORDER_QHULL,
+                  "hybrid: hull_order must be PCFIT_HULL_ORDER_CANONICAL (0) or PCFIT_HULL_ORDER_QHULL (1)");
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
     if (n_slices == 0) return PCFIT_OK;
@@ -1006,8 +1048,8 @@ PCFIT_API int pcfit_hybrid_batch(const double *x, const double *y, const int64_t
     PCFIT_TRY(dy.upload(y, total * 8, st));
     PCFIT_TRY(doff.upload(offsets, (S + 1) * 8, st));
     return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
-                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, hull_start, seed, status, fit, ux,
-                       uy, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal,
+                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, hull_start, hull_order, seed, status,
+                       fit, ux, uy, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal,
                        dev_uniform, grid_len, total, st);
 }
 
@@ -1080,11 +1122,13 @@ __global__ __launch_bounds__(64) void z_range_final_kernel(const double *__restr
 // bin the resident scan into the windows and run the chain on the slices
 static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                        double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
-                       double huber_delta, int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status,
-                       double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x, double *cand_y,
-                       uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin, double *ov_scal,
-                       double *dev_uniform, int64_t grid_len, int64_t cand_capacity, hipStream_t st)
+                       double huber_delta, int32_t use_hull, int32_t hull_order, uint64_t seed, int64_t *offsets,
+                       int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                       double *cand_y, uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin,
+                       double *ov_scal, double *dev_uniform, int64_t grid_len, int64_t cand_capacity, hipStream_t st)
 {
+    PCFIT_REQUIRE(hull_order == PCFIT_HULL_ORDER_CANONICAL || hull_order == PCFIT_HULL_ORDER_QHULL,
+                  "scan_hybrid: hull_order must be PCFIT_HULL_ORDER_CANONICAL (0) or PCFIT_HULL_ORDER_QHULL (1)");
     PCFIT_REQUIRE(n_points >= 0 && S >= 1, "scan_hybrid: need n_points >= 0 and n_slices >= 1");
     PCFIT_REQUIRE(z_lo && z_hi && offsets, "scan_hybrid: null pointer");
     PCFIT_REQUIRE(status && fit && n_unique && cand_offsets && argmax_argmin && ov_scal, "scan_hybrid: null pointer");
@@ -1096,8 +1140,8 @@ static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo,
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
     return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
-                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, seed, status, fit,
-                       nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,
+                       max_trials, min_inliers_frac, r_range, huber_delta, use_hull, nullptr, hull_order, seed, status,
+                       fit, nullptr, nullptr, n_unique, cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin,
                        ov_scal, dev_uniform, grid_len, cand_capacity, st);
 }
 
@@ -1106,7 +1150,8 @@ static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo,
 PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi,
                                       int64_t n_slices, double inlier_tol, int32_t max_trials,
                                       double min_inliers_frac, const double *r_range, double huber_delta,
-                                      int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status, double *fit,
+                                      int32_t use_hull, int32_t hull_order, uint64_t seed, int64_t *offsets,
+                                      int32_t *status, double *fit,
                                       int64_t *n_unique, int64_t *cand_offsets, double *cand_x, double *cand_y,
                                       uint8_t *mask, double *radius, double *theta, int64_t *argmax_argmin,
                                       double *ov_scal, double *dev_uniform, int64_t grid_len, int64_t cand_capacity)
@@ -1117,8 +1162,9 @@ PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const
     DevBuf dxyz;                   // the scan goes to the device once; slices are formed and stay there
     PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
     return scan_hybrid(dxyz.as<double>(), n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials, min_inliers_frac,
-                       r_range, huber_delta, use_hull, seed, offsets, status, fit, n_unique, cand_offsets, cand_x,
-                       cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len, cand_capacity, st);
+                       r_range, huber_delta, use_hull, hull_order, seed, offsets, status, fit, n_unique, cand_offsets,
+                       cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len, cand_capacity,
+                       st);
 }
 
 PCFIT_API int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan **scan, double *z_min_max)
@@ -1163,8 +1209,8 @@ PCFIT_API int pcfit_scan_free(pcfit_scan *scan)
 PCFIT_API int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z_lo, const double *z_hi,
                                          int64_t n_slices, double inlier_tol, int32_t max_trials,
                                          double min_inliers_frac, const double *r_range, double huber_delta,
-                                         int32_t use_hull, uint64_t seed, int64_t *offsets, int32_t *status,
-                                         double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
+                                         int32_t use_hull, int32_t hull_order, uint64_t seed, int64_t *offsets,
+                                         int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
                                          double *cand_y, uint8_t *mask, double *radius, double *theta,
                                          int64_t *argmax_argmin, double *ov_scal, double *dev_uniform,
                                          int64_t grid_len, int64_t cand_capacity)
@@ -1176,7 +1222,7 @@ PCFIT_API int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z
     PCFIT_REQUIRE(dev == scan->device, "scan_hybrid: the scan lives on device %d, the current device is %d",
                   scan->device, dev);
     return scan_hybrid(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials,
-                       min_inliers_frac, r_range, huber_delta, use_hull, seed, offsets, status, fit, n_unique,
+                       min_inliers_frac, r_range, huber_delta, use_hull, hull_order, seed, offsets, status, fit, n_unique,
                        cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len,
                        cand_capacity, nullptr);
 }

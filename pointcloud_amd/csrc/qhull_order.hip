@@ -597,9 +597,6 @@ __global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restr
 
 }  // namespace
 
-static std::atomic<int> g_hull_order{0};
-int hull_order_mode() { return g_hull_order.load(std::memory_order_relaxed); }
-
 int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                      int64_t n_slices, int32_t n_threads, const int64_t *select, int64_t *start, uint8_t *sure,
                      int64_t *walk, int64_t *n_walk)
@@ -607,7 +604,10 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
     const int T = (int)std::max<int64_t>(
         1, std::min<int64_t>(n_slices, n_threads > 0 ? n_threads
                                                     : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()))));
+    // a worker that runs out of memory must not end the process: it notes the failure and the call reports it
+    std::atomic<int> failed{0};
     auto work = [&](int t) {
+        try {
         for (int64_t s = t; s < n_slices; s += T) {
             const int64_t off = offsets[s], m = n_unique ? n_unique[s] : offsets[s + 1] - offsets[s];
             start[s] = -1;
@@ -622,13 +622,25 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
             if (sure) sure[s] = r.sure() ? 1 : 0;
             if (n_walk) n_walk[s] = r.count();
         }
+        } catch (...) {
+            failed.store(1, std::memory_order_relaxed);
+        }
     };
     if (T == 1)
         work(0);
     else {
         std::vector<std::thread> pool;
-        for (int t = 0; t < T; t++) pool.emplace_back(work, t);
+        try {
+            for (int t = 1; t < T; t++) pool.emplace_back(work, t);
+        } catch (...) {                       // no more threads: the strides of the missing ones stay undone
+            failed.store(1, std::memory_order_relaxed);
+        }
+        work(0);
         for (auto &th : pool) th.join();
+    }
+    if (failed.load()) {
+        set_error("qhull_order: out of host memory or threads during the replay");
+        return PCFIT_ERR_INVALID;
     }
     return PCFIT_OK;
 }
@@ -663,16 +675,3 @@ PCFIT_API int pcfit_qhull_order_batch(const double *ux, const double *uy, const 
     }
 }
 
-PCFIT_API int pcfit_set_hull_order(int32_t order)
-{
-    PCFIT_REQUIRE(order == 0 || order == 1, "set_hull_order: 0 (from the lexicographic minimum) or 1 (Qhull's)");
-    g_hull_order.store(order, std::memory_order_relaxed);
-    return PCFIT_OK;
-}
-
-PCFIT_API int pcfit_get_hull_order(int32_t *order)
-{
-    PCFIT_REQUIRE(order, "get_hull_order: null pointer");
-    *order = hull_order_mode();
-    return PCFIT_OK;
-}

@@ -96,7 +96,7 @@ def fit_circle_hybrid_at_z(
     the candidates, the sampled triples and with them the fit are then the
     reference's own.  "canonical": at the lexicographically smallest vertex (no
     replay).  An int: at that vertex, an index into the sorted distinct slice
-    points.  None: where ``pointcloud_amd.set_hull_order`` says.
+    points.
     """
     points_xyz = np.asarray(points_xyz)
     if points_xyz.ndim != 2 or points_xyz.shape[1] != 3:
@@ -106,12 +106,14 @@ def fit_circle_hybrid_at_z(
     offsets, x, y, _ = _ffi.bin_slices(points_xyz, lo, hi, want_perm=False)
     if offsets[1] < 3:
         return None
-    if hull_start == "canonical":
-        hs = np.array([-1], np.int64)
+    if isinstance(hull_start, str):
+        hs, order = None, hull_start                       # "qhull" / "canonical" (anything else is refused below)
     else:
-        hs = hull_start if hull_start is None or isinstance(hull_start, str) else np.array([hull_start], np.int64)
+        if hull_start is None:
+            raise ValueError('hull_start: "qhull", "canonical" or a vertex index')
+        hs, order = np.array([hull_start], np.int64), "canonical"
     h = _ffi.hybrid_batch(x, y, offsets, inlier_tol, max_trials, min_inliers_frac, r_range, huber_delta,
-                          use_hull_vertices_only, hs, want_profile=False)
+                          use_hull_vertices_only, hs, want_profile=False, order=order)
     if h["status"][0] != 0:
         return None
     nu = int(h["n_unique"][0])

@@ -1,7 +1,8 @@
 """Randomised comparison of the device replay of Qhull's construction (through pcfit_unique_hull_batch with
 hull_start = PCFIT_HULL_START_QHULL: device kernel first, host replay for what it hands back) with the host
 replay alone (pcfit_qhull_order_batch, itself checked against scipy by tests/sweep_qhull_order.py).  Needs a GPU.
-Not collected by pytest:  python tests/sweep_qhull_device.py [rounds] [seed]"""
+By hand:  python tests/sweep_qhull_device.py [rounds] [seed]; tests/test_randomised.py runs a few fixed-seed
+rounds of it under pytest."""
 import os
 import sys
 import time
@@ -63,8 +64,7 @@ def main(rounds=20, seed=0):
                       "sure", bool(host["sure"][s]))
         # the route of the analyzer (nobody asks for the distinct points: the replay reads the slices as they are,
         # unsorted and with their duplicates) against the route over the sorted distinct points
-        with F.hull_order("qhull"):
-            raw = F.hybrid_batch(x, y, off, max_trials=64, want_unique=False, want_profile=False)
+        raw = F.hybrid_batch(x, y, off, max_trials=64, want_unique=False, want_profile=False, order="qhull")
         srt = F.hybrid_batch(x, y, off, max_trials=64, hull_start="qhull", want_unique=True, want_profile=False)
         for key in ("status", "cand_offsets", "cand_x", "cand_y", "mask"):
             if not np.array_equal(raw[key], srt[key]):
@@ -83,8 +83,8 @@ def main(rounds=20, seed=0):
     print(f"{rounds} rounds, {slices} slices, {points} points, {time.time() - t0:.0f} s: {bad} differences "
           f"(and {open_} on slices the host replay is not sure of); {quant} slices with rounded coordinates; "
           f"handed back to the host {handed} ({why_all[:14].tolist()})")
-    return bad
+    return bad, open_, slices
 
 
 if __name__ == "__main__":
-    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3])) else 0)
+    sys.exit(1 if main(*(int(a) for a in sys.argv[1:3]))[0] else 0)

@@ -144,18 +144,18 @@ def test_hybrid_in_qhulls_order_is_the_reference_without_hints():
             continue
         first = {F.HULL_START_QHULL: int(q[0]), -1: 0}.get(int(want[i]), int(want[i]))
         assert walk[0] == first and same_cycle(walk, q), i
-    # the process-wide setting does the same for calls that name no start (and for the scan forms)
-    hy_named = F.hybrid_batch(x, y, off, max_trials=800, hull_start="qhull", want_profile=False)
-    F.set_hull_order("qhull")
-    try:
-        assert F.get_hull_order() == "qhull"
-        hy_set = F.hybrid_batch(x, y, off, max_trials=800, want_profile=False)
-        pts = np.concatenate([np.column_stack([xs[i], ys[i], np.full(len(xs[i]), 2.0 * i)]) for i in range(10)])
-        zc = 2.0 * np.arange(10)
-        sc = F.scan_hybrid_batch(pts, zc - 0.5, zc + 0.5, max_trials=800, want_profile=False)
-    finally:
-        F.set_hull_order("canonical")
-    assert F.get_hull_order() == "canonical"
+    # the order as an argument of the call (the default of the Python layer) does the same as naming Qhull's
+    # vertex slice by slice, in the batch form and in the scan forms
+    hy_named = F.hybrid_batch(x, y, off, max_trials=800, hull_start="qhull", want_profile=False, order="canonical")
+    hy_set = F.hybrid_batch(x, y, off, max_trials=800, want_profile=False)
+    pts = np.concatenate([np.column_stack([xs[i], ys[i], np.full(len(xs[i]), 2.0 * i)]) for i in range(10)])
+    zc = 2.0 * np.arange(10)
+    sc = F.scan_hybrid_batch(pts, zc - 0.5, zc + 0.5, max_trials=800, want_profile=False)
+    with pytest.raises(ValueError):
+        F.hybrid_batch(x, y, off, max_trials=8, order="other")
+    assert F.lib().pcfit_hybrid_batch(F._p(x), F._p(y), F._p(off), 10, 0.5, 8, 0.1, None, 1.0, 1, None, 7, 42,
+                                      *([None] * 14), 1024) == -1                 # an order that does not exist
+    assert b"hull_order" in F.lib().pcfit_last_error()
     for k in ("status", "cand_offsets", "cand_x", "cand_y", "mask", "fit"):
         assert np.array_equal(hy_named[k], hy_set[k], equal_nan=k == "fit"), k
         assert np.array_equal(hy_named[k], sc[k], equal_nan=k == "fit"), k
@@ -547,18 +547,12 @@ def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
     """The analyzer as it comes (Config.hull_order = "qhull"): its candidates are the reference's
     `xy[hull.vertices]` in the reference's order, so every slice - the three whose hull holds outliers included -
     has the reference's boundary points, fit and metrics (tests/golden/analyzer.npz, recorded from the reference
-    itself); the process-wide switch with a configuration that leaves the order open does the same."""
+    itself)."""
     import pointcloud_amd as P
     g = load_golden("analyzer")
     pts = analyzer_points()
     res = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000)).analyze_with_progress(pts)
-    P.set_hull_order("qhull")
-    try:
-        az = P.CylinderAnalyzer(P.Config(z_step=2.0, min_points_per_slice=1000, hull_order=None))
-        assert az.analyze_with_progress(pts) == res
-    finally:
-        P.set_hull_order("canonical")
-    assert P.get_hull_order() == "canonical"
+    assert not hasattr(P, "set_hull_order") and not hasattr(F.lib(), "pcfit_set_hull_order")   # no process-wide switch
     assert len(res) == int(g["n_results"])
     mine = np.array([[r[k] for k in SCALARS] for r in res], dtype=float)
     ref = g["scalars"]
@@ -717,7 +711,8 @@ def test_dropin_function_contracts():
 
 # ------------------------------------------------------------------ full-size configurations
 def test_full_size_fit_residual_pass():
-    """10 000 slices x 8192 points: the whole batch on the GPU, 48 slices replayed on the CPU."""
+    """10 000 slices x 8192 points: the whole batch on the GPU, 48 slices replayed on the CPU - through the
+    three separate calls and through the one launch that bench.py times (pcfit_fit_residuals_batch_dev)."""
     S, n = 10_000, 8192
     x, y, off = R.make_slices(S, n, seed=1, jitter=0.02)
     fit_k, st = F.kasa_batch(x, y, off)
@@ -726,6 +721,10 @@ def test_full_size_fit_residual_pass():
     assert np.all(st == 0) and np.all(iters[:, 0] == 100)
     assert np.all(res["hist"].sum(axis=1) == n)                   # 10 sigma range holds every point
     assert abs(np.median(fit[:, 2]) - 10.0) < 0.02
+    one = _fused_dev(x, y, off, 256, -0.5, 0.5)                  # the timed launch of bench.py, at its own size
+    assert np.all(one["status"] == 0) and np.all(one["iters"][:, 0] == 100)
+    assert np.all(one["hist"].sum(axis=1) == n)
+    assert rel(one["fit"], fit) < 1e-9 and rel(one["kasa"], fit_k) < 1e-11
     for s in np.random.default_rng(0).choice(S, 48, replace=False):
         sl = slice(off[s], off[s + 1])
         so, ko = N.kasa(x[sl], y[sl])
@@ -736,6 +735,11 @@ def test_full_size_fit_residual_pass():
         assert np.array_equal(o["hist"], res["hist"][s])
         assert (o["argmax"], o["argmin"], o["rmax"], o["rmin"]) == (res["argmax"][s], res["argmin"][s],
                                                                     res["rmax"][s], res["rmin"][s])
+        # the one launch: fit against the literal C loop, statistics against the C restatement at its own fit
+        assert rel(one["kasa"][s], ko) < 1e-11 and rel(one["fit"][s], lo_) < 1e-9
+        o1 = N.residuals(np.stack([x[sl], y[sl]], 1), *one["fit"][s], bins=256, lo=-0.5, hi=0.5, per_point=False)
+        assert np.array_equal(o1["hist"], one["hist"][s])
+        assert (o1["argmax"], o1["argmin"]) == tuple(one["amm"][s]) and (o1["rmax"], o1["rmin"]) == tuple(one["rmm"][s])
 
 
 def test_fused_fit_residual_launch_equals_the_separate_kernels():
@@ -1120,10 +1124,10 @@ def test_unique_hull_on_slices_longer_than_lds():
         want = h["hull_idx"][o:o + nh]
         k = 0 if starts[s] < 0 else nh // 3
         assert np.array_equal(h2["hull_idx"][o:o + nh], np.concatenate([want[k:], want[:k]])), s
-    lean = F.hybrid_batch(x, y, off, max_trials=50, want_unique=False, want_profile=False)
+    lean = F.hybrid_batch(x, y, off, max_trials=50, want_unique=False, want_profile=False, order="canonical")
     full = np.array([len(R.unique_rows(xy)) for xy in sets])
     assert np.all(lean["n_unique"] <= full) and lean["n_unique"][1] < 0.3 * full[1] and lean["n_unique"][5] == full[5]
-    hy = F.hybrid_batch(x, y, off, max_trials=300)
+    hy = F.hybrid_batch(x, y, off, max_trials=300, order="canonical")
     assert np.all(hy["status"] == 0)
     for s, xy in enumerate(sets):
         ref = R.hybrid_fit(np.column_stack([xy, np.zeros(len(xy))]), 0.0, 1.0, max_trials=300)
@@ -1495,9 +1499,9 @@ def test_calls_from_several_threads_at_once():
         x, y, off = R.make_slices(3 + k % 4, 700 + 450 * k, seed=100 + k, outlier_frac=0.05 * (k % 3))
         jobs.append((x, y, off))
 
-    def run(job):
+    def run(job, order="qhull"):
         x, y, off = job
-        h = F.hybrid_batch(x, y, off, max_trials=500, want_profile=False)
+        h = F.hybrid_batch(x, y, off, max_trials=500, want_profile=False, order=order)
         k, _ = F.kasa_batch(x, y, off)
         return h["fit"], h["mask"], h["cand_x"], k
 
@@ -1508,6 +1512,34 @@ def test_calls_from_several_threads_at_once():
         for a, b in zip(serial, parallel):
             for u, v in zip(a, b):
                 assert np.array_equal(u, v, equal_nan=True)
+
+    # Six analyzers at once on scans whose hulls hold outliers (so that the candidate order decides the sampled
+    # triples and the fits), half of them in Qhull's order, half from the lexicographic minimum: the order is an
+    # argument of each call, so every analysis equals its own serial run whatever the others ask for
+    from pointcloud_amd import Config, CylinderAnalyzer
+    from pointcloud_amd.synth import make_cylinder
+    work = []
+    for k in range(6):
+        pts = make_cylinder(60_000, 12, seed=300 + k, outlier_frac=0.05)
+        order = ("qhull", "canonical")[k % 2]
+        work.append((CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500, hull_order=order)), pts))
+    alone = [az.analyze_with_progress(pts) for az, pts in work]
+    for _ in range(3):
+        with ThreadPoolExecutor(6) as pool:
+            together = list(pool.map(lambda w: w[0].analyze_with_progress(w[1]), work))
+        assert together == alone
+    # (the two orders do differ on this data: the test would not notice a shared switch otherwise)
+    other = [CylinderAnalyzer(Config(z_step=2.0, min_points_per_slice=500,
+                                     hull_order=("canonical", "qhull")[k % 2])).analyze_with_progress(work[k][1])
+             for k in range(6)]
+    assert sum(a != b for a, b in zip(alone, other)) >= 3
+    jobs_mixed = [(j, ("qhull", "canonical")[k % 2]) for k, j in enumerate(jobs)]
+    serial = [run(j, o) for j, o in jobs_mixed]
+    with ThreadPoolExecutor(6) as pool:
+        parallel = list(pool.map(lambda a: run(*a), jobs_mixed))
+    for a, b in zip(serial, parallel):
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v, equal_nan=True)
 
 
 def test_device_entry_points_can_be_captured_in_a_hip_graph():
