@@ -125,17 +125,25 @@ struct SliceView {
         // the compiler from weaving the arithmetic in between, which left eight loads in flight per wave and a
         // workgroup waiting four times as long for its 128 KB): the memory system then sees the whole slice at once.
         if (!STREAM && n == (PT_R + PT_L) * FIT_BLOCK) {
-            // a slice that fills the storage
+            // a slice that fills the storage (byte offsets in 32 bits - the storage holds far less than 4 GB -
+            // so that a load's address is the uniform base plus one vector register, not a 64-bit vector sum)
+            // (the thread's own bytes lie below FIT_BLOCK * 8, a power of two: the two parts of an offset share
+            // no bit, and joined by "or" the compiler sees that nothing carries)
+            static_assert((FIT_BLOCK & (FIT_BLOCK - 1)) == 0, "offsets are joined bit by bit");
+            auto at = [](const double *base, uint32_t k) {
+                const uint32_t bytes = (threadIdx.x * 8u) | (k * (uint32_t)FIT_BLOCK * 8u);
+                return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + bytes);
+            };
 #pragma unroll
             for (int k = 0; k < PT_R; k++) {
-                rx[k] = xs[threadIdx.x + k * FIT_BLOCK];
-                ry[k] = ys[threadIdx.x + k * FIT_BLOCK];
+                rx[k] = at(xs, k);
+                ry[k] = at(ys, k);
             }
             double tx[PT_L > 0 ? PT_L : 1], ty[PT_L > 0 ? PT_L : 1];
 #pragma unroll
             for (int k = 0; k < PT_L; k++) {
-                tx[k] = xs[threadIdx.x + (PT_R + k) * FIT_BLOCK];
-                ty[k] = ys[threadIdx.x + (PT_R + k) * FIT_BLOCK];
+                tx[k] = at(xs, PT_R + k);
+                ty[k] = at(ys, PT_R + k);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -369,11 +377,11 @@ __device__ __forceinline__ void each_point(const View &P, F &&f)
 }
 
 // Static LDS of a fit kernel, in doubles: two scratch areas for the workgroup
-// reductions (17 values x 16 waves each, used alternately) and two areas for
+// reductions (up to 16 values x 16 waves each, used alternately) and two areas for
 // totals (12 sums, the smallest and the largest distance, three model sums), and 16 doubles through which the
 // first wave hands the others what it has worked out alone (the Kasa circle; the LM loop's next candidate, in
 // the end its result).
-constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE = RED_TOT + 2 * RED_AREA,
+constexpr int RED_SCR = 16 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE = RED_TOT + 2 * RED_AREA,
               RED_STATE = RED_SHARE + 16, RED_SIZE = RED_STATE + LM_STATE_DOUBLES;
 
 // Where the next reduction of a workgroup puts its partial sums.  Alternating
@@ -386,6 +394,7 @@ constexpr int RED_SCR = 17 * 16, RED_AREA = 24, RED_TOT = 2 * RED_SCR, RED_SHARE
 // that wave's SIMD carried a third more instructions for the slice than the other three.
 struct RedCtx {
     double *lds;
+    double *lohi;               // where a sweep's reduction leaves the quads' extreme distances (LM kernels only)
     int count;
     int first_owner, turn, waves;
     __device__ __forceinline__ double *scratch() { return lds + (count++ & 1) * RED_SCR; }
@@ -396,10 +405,13 @@ struct RedCtx {
     __device__ __forceinline__ void next_owner() { turn++; }
 };
 
-__device__ __forceinline__ RedCtx make_red(double *lds)
+// doubles of LDS an LM kernel of B threads sets aside for RedCtx::lohi
+constexpr int red_lohi_doubles(int B) { return 2 * (B / WAVE) * 16; }
+
+__device__ __forceinline__ RedCtx make_red(double *lds, double *lohi = nullptr)
 {
     const int waves = (int)(blockDim.x >> 6);
-    return RedCtx{lds, 0, (int)(blockIdx.x % (unsigned)waves), 0, waves};
+    return RedCtx{lds, lohi, 0, (int)(blockIdx.x % (unsigned)waves), 0, waves};
 }
 
 // circle_fitting.py:35-54.  Uniform result in every thread.
@@ -554,7 +566,6 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     const double r = ri - pr;
                     high = max_no_nan(high, ri);
                     const double j0 = -dx * iv, j1 = -dy * iv;
-                    acc[10] = fma(r, r, acc[10]);
                     acc[0] = fma(j0, j0, acc[0]);
                     acc[1] = fma(j0, j1, acc[1]);
                     acc[2] = acc[2] - j0;
@@ -562,8 +573,12 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
                     acc[6] = fma(j0, r, acc[6]);
                     acc[7] = fma(j1, r, acc[7]);
                     acc[8] = acc[8] - r;
-                    acc[9] = fma(fabs(r), iv, acc[9]);
+                    // (the first sweep's cost and curvature sum are never read: the loop starts from a last cost
+                    // of infinity, takes the first candidate whatever it costs, and the bounds that use the
+                    // curvature wait for a finite last cost)
                     if constexpr (MODEL_SUMS) {
+                        acc[10] = fma(r, r, acc[10]);
+                        acc[9] = fma(fabs(r), iv, acc[9]);
                         const double q = r * iv, t0 = j0 * q;
                         acc[12] = fma(t0, j0, acc[12]);
                         acc[13] = fma(t0, j1, acc[13]);
@@ -578,13 +593,14 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
             // zero gives here as well) that the sum of squares has kept
             // (the largest |residual| sits at the largest or at the smallest distance; without points -inf)
             const double amax = max_no_nan(high - pr, pr - low);
-            const bool odd = !(amax <= delta) || acc[10] != acc[10] || low < 1e-6;
+            // (the sum of the residuals has kept any NaN as well as the sum of their squares)
+            const bool odd = !(amax <= delta) || acc[8] != acc[8] || low < 1e-6;
             acc[5] = (double)P.full_points_per_thread();      // the sum of that many ones (j2 = -1)
             acc[3] = acc[5] - acc[0];                           // j0^2 + j1^2 = d2 / d2 = 1 for every point
             P.ragged_group(ragged);
             low = odd ? -inf : low;             // the smallest distance doubles as the flag
             ph.mark(2);
-            block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot, red.owner());
+            block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), red.lohi, tot, red.owner());
             ph.mark(3);
             return;
         }
@@ -596,7 +612,7 @@ __device__ __forceinline__ bool lm_slice(const View &P, const LmParams prm, RedC
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { any_point(px, py, i0, false, std::false_type{}); });
         P.ragged_group(ragged);
         ph.mark(2);
-        block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), tot, red.owner());
+        block_reduce_to_lds2<15, NW, 12, false>(acc, low, high, red.scratch(), red.lohi, tot, red.owner());
         ph.mark(3);
     };
 
@@ -718,9 +734,10 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void lm_kernel(const double *__restri
                                                       double *__restrict__ out, int32_t *__restrict__ iters)
 {
     __shared__ double lds[RED_SIZE];
+    __shared__ double lohi[red_lohi_doubles(FIT_BLOCK)];
     Phase ph;
     ph.init();
-    RedCtx red = make_red(lds);
+    RedCtx red = make_red(lds, lohi);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
@@ -750,9 +767,10 @@ __global__ __launch_bounds__(FIT_BLOCK, 2) void fit_kernel(const double *__restr
                                                        int32_t *__restrict__ iters, int32_t *__restrict__ status)
 {
     __shared__ double lds[RED_SIZE];
+    __shared__ double lohi[red_lohi_doubles(FIT_BLOCK)];
     Phase ph;
     ph.init();
-    RedCtx red = make_red(lds);
+    RedCtx red = make_red(lds, lohi);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;
@@ -981,10 +999,26 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
         P.full_groups([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, false); });
     }
     P.ragged_group([&](const double (&px)[U], const double (&py)[U], int32_t i0) { exact_group(px, py, i0, true); });
-    fold_extremes<32>(mx, mn, lane);
-    if (lane == 0) {
-        wmax[wave] = mx;
-        wmin[wave] = mn;
+    // The wave's extremes.  On the quick road a lane holds a candidate only when one of its points went through
+    // the exact code - the slice's extremes themselves and little else - so a wave has none, or one lane has
+    // one: that lane writes it and the six-step fold of (radius, index) pairs over the lanes, some 170
+    // instructions a thread, is left to the waves where several lanes hold candidates.
+    {
+        const mask_t has_max = __builtin_amdgcn_ballot_w64(mx.i >= 0), has_min = __builtin_amdgcn_ballot_w64(mn.i >= 0);
+        if (__popcll(has_max) > 1 || __popcll(has_min) > 1) {
+            fold_extremes<32>(mx, mn, lane);
+            if (lane == 0) {
+                wmax[wave] = mx;
+                wmin[wave] = mn;
+            }
+        } else {
+            // (a lane without a candidate holds (-inf, -1) / (+inf, -1), which is what a wave without one reports)
+            const int at_max = has_max ? (int)__builtin_ctzll(has_max) : 0, at_min = has_min ? (int)__builtin_ctzll(has_min) : 0;
+            if (lane == at_max)
+                wmax[wave] = mx;
+            if (lane == at_min)
+                wmin[wave] = mn;
+        }
     }
     __syncthreads();
     const int32_t *lhist = reinterpret_cast<const int32_t *>(lds_dyn) + 2 * (base + H + 1);
@@ -995,6 +1029,8 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
         hist[s * H + b] = (int64_t)c;
     }
     if (threadIdx.x == 0) {
+        mx = wmax[0];
+        mn = wmin[0];
         for (int w = 1; w < nw; w++) {
             mx = better_max(mx, wmax[w]);
             mn = better_min(mn, wmin[w]);
@@ -1023,12 +1059,13 @@ __global__ __launch_bounds__(FIT_BLOCK, (GIVEN ? 4 : !WITH_LM && PT_L == 10 ? 3 
 {
     static_assert(!GIVEN || !WITH_LM, "a given circle is not refined");
     __shared__ double lds[RED_SIZE];
+    __shared__ double lohi[WITH_LM ? red_lohi_doubles(FIT_BLOCK) : 1];
     __shared__ Extreme2 wmax[16], wmin[16];
     __shared__ double wthr[2 * 16];
     __shared__ int edges_off;           // set when the edges are not uniformly spaced
     Phase ph;
     ph.init();
-    RedCtx red = make_red(lds);
+    RedCtx red = make_red(lds, lohi);
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     SliceView<PT_R, PT_L, FIT_BLOCK> P;

@@ -389,12 +389,16 @@ __device__ __forceinline__ void lm_step(LmState &st, const LmParams &prm, const 
                 break;
             }
             if constexpr (MODEL) {
-                if (st.regular && lm_regular_all_rejected(st, prm, hg, gd)) {
+                // (the second test first: it is the one that holds on the usual course - start, one accepted
+                // candidate, one modelled step - and the two cannot hold together, one proving that this
+                // candidate is accepted, the other that none is; so their order decides nothing but the cost)
+                double slack;
+                const bool last = st.regular && lm_model_step_is_last(st, prm, hg, slack);
+                if (!last && st.regular && lm_regular_all_rejected(st, prm, hg, gd)) {
                     st.it = prm.max_iter;
                     break;
                 }
-                double slack;
-                if (st.regular && lm_model_step_is_last(st, prm, hg, slack)) {
+                if (last) {
                     // (how far the centre really goes: far from the origin the rounding of the two sums can exceed
                     // the step itself, and the bounds below must hold for the centre that is returned)
                     const double ncx = st.cx + st.step[0], ncy = st.cy + st.step[1];

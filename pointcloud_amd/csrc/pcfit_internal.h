@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "pcfit.h"
 
@@ -493,26 +494,61 @@ __device__ __forceinline__ double wave_max(double v)
     return wave_fold<32>(v, (int)(threadIdx.x & 63), [](double a, double b) { return fmax(a, b); });
 }
 
+// min over the four lanes of a quad (every lane of the quad ends with it): two quad permutes, no copy first
+// (every lane receives a value, so what the destination held before does not matter)
+__device__ __forceinline__ double quad_min(double v)
+{
+    auto from = [](double x, auto ctrl) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), decltype(ctrl)::value, 0xf, 0xf, false);
+        return __hiloint2double(hi, lo);
+    };
+    v = min_no_nan(v, from(v, std::integral_constant<int, DPP_QUAD_XOR1>{}));
+    return min_no_nan(v, from(v, std::integral_constant<int, DPP_QUAD_XOR2>{}));
+}
+
 // The same with two extremes: the smallest `low` at dst[AT] and the largest `high` at dst[AT + 1]; the sums
-// from the AT-th on follow them (sum k at dst[k + 2]).  scratch: (K + 2) * 16 doubles.
+// from the AT-th on follow them (sum k at dst[k + 2]).  scratch: K * 16 doubles; lohi: 2 * NW * 16 doubles
+// (one area, not two in turn: between the owner's reads and the next call's writes lies the barrier
+// through which the owner hands its step to the others).
+// The two extremes take the cheap road: a fold over the lanes of every wave would cost some 80 instructions
+// on each of them (two values, six exchanges of two moves each, the operation); here a quad folds by two
+// permutes, one lane in four leaves the quad's pair in LDS, and after the barrier the owning wave alone
+// folds them - its lower half the smallest distances, its upper half the largest, negated, so that one chain
+// of minima serves both.
 template <int K, int NW, int AT = K, bool END_BARRIER = true>
 __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low, double high, double *scratch,
-                                                     double *dst, int owner = 0)
+                                                     double *lohi, double *dst, int owner = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int tid = (int)threadIdx.x - owner * 64;
     rs_steps<K, 32>(v, lane);
     bool valid = true;
     const int k = rs_index<K, 32>(lane, valid);
-    low = wave_min(low);
-    high = wave_max(high);
+    low = quad_min(low);
+    high = quad_min(-high);
     if (valid && (lane & rs_lowmask<K, 32>()) == 0)
         scratch[k * 16 + wave] = v[0];
-    if (lane == 0) {
-        scratch[K * 16 + wave] = low;
-        scratch[(K + 1) * 16 + wave] = high;
+    if ((lane & 3) == 0) {
+        lohi[wave * 16 + (lane >> 2)] = low;
+        lohi[NW * 16 + wave * 16 + (lane >> 2)] = high;
     }
     __syncthreads();
+    if (wave == owner) {                        // (uniform over the wave: all its lanes take part in the exchanges)
+        // NW * 16 values of either kind: lane l of a half takes those at l, l + 32, ...
+        constexpr int PER = NW * 16, READS = (PER + 31) / 32;
+        const double *src = lohi + (lane >> 5) * PER;
+        const int l5 = lane & 31;
+        double m = src[l5 < PER ? l5 : PER - 1];
+#pragma unroll
+        for (int j = 1; j < READS; j++)
+            m = min_no_nan(m, src[l5 + 32 * j < PER ? l5 + 32 * j : PER - 1]);
+        m = wave_fold<16>(m, lane, [](double a, double b) { return min_no_nan(a, b); });
+        if (lane == 0)
+            dst[AT] = m;
+        if (lane == 32)
+            dst[AT + 1] = -m;
+    }
     if (tid >= 0 && tid < K) {
         double part[NW];
 #pragma unroll
@@ -523,18 +559,6 @@ __device__ __forceinline__ void block_reduce_to_lds2(double (&v)[K], double low,
         for (int w = 1; w < NW; w++)
             s += part[w];
         dst[tid < AT ? tid : tid + 2] = s;
-    } else if (tid == K) {
-        double s = scratch[K * 16];
-#pragma unroll
-        for (int w = 1; w < NW; w++)
-            s = fmin(s, scratch[K * 16 + w]);
-        dst[AT] = s;
-    } else if (tid == K + 1) {
-        double s = scratch[(K + 1) * 16];
-#pragma unroll
-        for (int w = 1; w < NW; w++)
-            s = fmax(s, scratch[(K + 1) * 16 + w]);
-        dst[AT + 1] = s;
     }
     if constexpr (END_BARRIER)
         __syncthreads();
