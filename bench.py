@@ -258,13 +258,21 @@ def extra_configs(L, dev, stream):
     amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
     ms_hist = timed(lambda: F.check(L.pcfit_residuals_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), None, None, None,
                                                                 H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream)), 3)
+    # both from one read of every window (pcfit_boundary_residuals_batch_dev), and that they are the same numbers
+    sel1, hist1, amm1 = torch.empty_like(sel), torch.empty_like(hist), torch.empty_like(amm)
+    ms_both = timed(lambda: F.check(L.pcfit_boundary_residuals_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), 720,
+                                                                         ptr(sel1), H, ptr(edges), ptr(hist1), ptr(rmm),
+                                                                         ptr(amm1), stream)), 3)
+    same = bool(torch.equal(sel, sel1) and torch.equal(hist, hist1) and torch.equal(amm, amm1))
     gbs = lambda ms_, passes: 16.0 * tot * passes / (ms_ * 1e-3) / 1e9
     out["boundary_and_histograms_100M_points_2000_windows"] = {
         "ms_binning": ms, "ms_kasa_lm_fit": ms_fit, "mean_lm_sweeps": sweeps,
         "ms_angular_bin_boundary_720": ms_sel, "ms_residual_histogram_256": ms_hist,
-        "ms_total": ms + ms_fit + ms_sel + ms_hist, "points_per_s": n / ((ms + ms_fit + ms_sel + ms_hist) * 1e-3),
+        "ms_boundary_and_histogram_one_sweep": ms_both, "one_sweep_equals_the_two_calls": same,
+        "hbm_gbs_one_sweep": gbs(ms_both, 1), "hbm_frac_one_sweep": gbs(ms_both, 1) / PEAK_HBM_GBS,
+        "ms_total": ms + ms_fit + ms_both, "points_per_s": n / ((ms + ms_fit + ms_both) * 1e-3),
         "longest_window": longest, "all_fits_ok": bool((st == 0).all().item()),
-        "hbm_gbs_boundary_two_passes": gbs(ms_sel, 2), "hbm_frac_boundary": gbs(ms_sel, 2) / PEAK_HBM_GBS,
+        "hbm_gbs_boundary": gbs(ms_sel, 1), "hbm_frac_boundary": gbs(ms_sel, 1) / PEAK_HBM_GBS,
         "hbm_gbs_histogram": gbs(ms_hist, 1), "hbm_frac_histogram": gbs(ms_hist, 1) / PEAK_HBM_GBS,
         "hbm_gbs_fit_per_sweep": gbs(ms_fit, sweeps + 1), "hbm_frac_fit_per_sweep": gbs(ms_fit, sweeps + 1) / PEAK_HBM_GBS}
     return out

@@ -257,6 +257,18 @@ int pcfit_residuals_batch_dev(const double *x, const double *y, const int64_t *o
 int pcfit_angle_max_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                               const double *cxcyr, int32_t bins, int64_t *sel, void *stream);
 
+/* ---- boundary and residual statistics about the same circle, one sweep ------------------------------ */
+/* boundary_by_angle_max (boundary.py:7-42: sel as pcfit_angle_max_batch_dev) and the residual statistics of
+ * pcfit_residuals_batch_dev without per-point outputs (gui.py:972-987, analyzer.py:83-92: hist, rmax_rmin,
+ * argmax_argmin) for every slice, each slice read from HBM once instead of three times: both start from a
+ * point's offsets from the centre and its distance.  The same indices, counts and extremes as the two calls.
+ * 1 <= bins <= 4096, 0 <= n_bins <= 4096 (edges: n_bins + 1 doubles in device memory), slices of up to
+ * 2^31 - 1 points. */
+int pcfit_boundary_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                       const double *cxcyr, int32_t bins, int64_t *sel, int32_t n_bins,
+                                       const double *edges, int64_t *hist, double *rmax_rmin,
+                                       int64_t *argmax_argmin, void *stream);
+
 /* ---- unique rows, rank check, hull: circle_fitting.py:14-19, 182-198 -- */
 /* ux, uy: the slice's distinct points sorted by (x, y), written at the slice's
  * own CSR offset; n_unique[s] of them (all of them, whatever the slice's
@@ -330,6 +342,9 @@ int pcfit_residuals_batch(const double *x, const double *y, const int64_t *offse
                           const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin);
 int pcfit_angle_max_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                           const double *cxcyr, int32_t bins, int64_t *sel);
+int pcfit_boundary_residuals_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
+                                   const double *cxcyr, int32_t bins, int64_t *sel, int32_t n_bins,
+                                   const double *edges, int64_t *hist, double *rmax_rmin, int64_t *argmax_argmin);
 /* offsets: S+1 out; x_out/y_out/perm: capacity entries (2*N always suffices);
  * *total receives offsets[S].  Returns PCFIT_ERR_INVALID if capacity is short. */
 int pcfit_bin_slices(const double *xyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,

@@ -74,6 +74,8 @@ SIGNATURES = {
                                                 _vp, _vp]),
     "pcfit_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_angle_max_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "pcfit_boundary_residuals_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "pcfit_boundary_residuals_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i32, _vp, _i32, _vp, _vp, _vp, _vp]),
     "pcfit_unique_hull_workspace_bytes": (_sz, [_i64, _i64]),
     "pcfit_unique_hull_batch_dev": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                                               _vp]),
@@ -245,6 +247,22 @@ def angle_max_batch(x, y, offsets, cxcyr, bins=720):
     sel = np.zeros((S, bins), np.int64)
     check(lib().pcfit_angle_max_batch(_p(x), _p(y), _p(offsets), S, _p(fit), bins, _p(sel)))
     return sel
+
+
+def boundary_residuals_batch(x, y, offsets, cxcyr, bins=720, hist_bins=0, lo=0.0, hi=1.0):
+    """angle_max_batch and the statistics of residuals_batch (no per-point outputs) about the same circles, each
+    slice read once (pcfit_boundary_residuals_batch)."""
+    x, y, offsets = as_csr(x, y, offsets)
+    S = offsets.size - 1
+    fit = _arr(cxcyr, np.float64).reshape(S, 3)
+    sel = np.zeros((S, bins), np.int64)
+    edges = np.linspace(lo, hi, hist_bins + 1) if hist_bins > 0 else None
+    hist = np.zeros((S, hist_bins), np.int64) if hist_bins > 0 else None
+    rmm = np.zeros((S, 2))
+    amm = np.zeros((S, 2), np.int64)
+    check(lib().pcfit_boundary_residuals_batch(_p(x), _p(y), _p(offsets), S, _p(fit), bins, _p(sel), hist_bins,
+                                               _p(edges), _p(hist), _p(rmm), _p(amm)))
+    return dict(sel=sel, hist=hist, rmax=rmm[:, 0], rmin=rmm[:, 1], argmax=amm[:, 0], argmin=amm[:, 1])
 
 
 def bin_slices(points, z_lo, z_hi, want_perm=True):

@@ -863,6 +863,44 @@ PCFIT_API int pcfit_residuals_batch(const double *x, const double *y, const int6
     return PCFIT_OK;
 }
 
+PCFIT_API int pcfit_boundary_residuals_batch(const double *x, const double *y, const int64_t *offsets,
+                                             int64_t n_slices, const double *cxcyr, int32_t bins, int64_t *sel,
+                                             int32_t n_bins, const double *edges, int64_t *hist, double *rmax_rmin,
+                                             int64_t *argmax_argmin)
+{
+    PCFIT_ENTER();
+    int64_t total, max_len;
+    PCFIT_TRY(check_offsets(offsets, n_slices, &total, &max_len));
+    if (n_slices == 0) return PCFIT_OK;
+    PCFIT_REQUIRE(cxcyr && sel && rmax_rmin && argmax_argmin && (total == 0 || (x && y)),
+                  "boundary_residuals: null pointer");
+    PCFIT_REQUIRE(bins >= 1 && n_bins >= 0, "boundary_residuals: bins must be >= 1, n_bins >= 0");
+    PCFIT_REQUIRE(n_bins == 0 || (edges && hist), "boundary_residuals: histogram asked for without edges/hist");
+    PCFIT_REQUIRE(max_len < 0x7fffffffll, "boundary_residuals: slice longer than 2^31-2 points");
+    hipStream_t st = nullptr;
+    DevBuf dx, dy, doff, dfit, dsel, dedge, dhist, drm, dam;
+    PCFIT_TRY(dx.upload(x, total * 8, st));
+    PCFIT_TRY(dy.upload(y, total * 8, st));
+    PCFIT_TRY(doff.upload(offsets, (n_slices + 1) * 8, st));
+    PCFIT_TRY(dfit.upload(cxcyr, n_slices * 24, st));
+    PCFIT_TRY(dsel.alloc((size_t)n_slices * bins * 8));
+    if (n_bins > 0) {
+        PCFIT_TRY(dedge.upload(edges, (size_t)(n_bins + 1) * 8, st));
+        PCFIT_TRY(dhist.alloc((size_t)n_slices * n_bins * 8));
+    }
+    PCFIT_TRY(drm.alloc(n_slices * 16));
+    PCFIT_TRY(dam.alloc(n_slices * 16));
+    PCFIT_TRY(pcfit_boundary_residuals_batch_dev(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), n_slices,
+                                                 dfit.as<double>(), bins, dsel.as<int64_t>(), n_bins, dedge.as<double>(),
+                                                 dhist.as<int64_t>(), drm.as<double>(), dam.as<int64_t>(), st));
+    PCFIT_TRY(dsel.download(sel, (size_t)n_slices * bins * 8, st));
+    if (n_bins > 0) PCFIT_TRY(dhist.download(hist, (size_t)n_slices * n_bins * 8, st));
+    PCFIT_TRY(drm.download(rmax_rmin, n_slices * 16, st));
+    PCFIT_TRY(dam.download(argmax_argmin, n_slices * 16, st));
+    PCFIT_HIP(hipStreamSynchronize(st));
+    return PCFIT_OK;
+}
+
 PCFIT_API int pcfit_angle_max_batch(const double *x, const double *y, const int64_t *offsets, int64_t n_slices,
                                     const double *cxcyr, int32_t bins, int64_t *sel)
 {

@@ -23,6 +23,7 @@
 
 #include "pcfit_internal.h"
 #include "fit_math.h"
+#include "angle_math.h"
 
 namespace pcfit {
 
@@ -860,12 +861,23 @@ __host__ __device__ __forceinline__ int hist_stride(int32_t H) { return H + 8; }
 // code: cr_hypot, numpy's guess-and-repair against the edges, and the (radius,
 // first index) comparison.  Slices whose parameters leave no such margins, and
 // the ragged end of every slice, take the exact code for all points.
-template <class View>
+// `also`: what else wants to see every point of the slice on this sweep (the angular-bin boundary of
+// boundary_residual_kernel): also.quick(dx, dy, r1, u) for point u of a group on the quick road, with its offsets
+// from the centre and its quick radius at hand, then also.quick_done(i0, stride) once per group (point u has index
+// i0 + u * stride); also.any(px, py, i, valid) for a point of the exact road.  Every point of the slice is handed
+// over exactly once.
+struct NoOtherUse {
+    __device__ __forceinline__ void quick(double, double, double, int) const {}
+    __device__ __forceinline__ void quick_done(int32_t, int32_t) const {}
+    __device__ __forceinline__ void any(double, double, int32_t, bool) const {}
+};
+
+template <class View, class Also = NoOtherUse>
 __device__ __forceinline__ void residual_slice(const View &P, double cx, double cy, double R, int32_t H, int32_t base,
                                                int64_t s, int64_t *__restrict__ hist, double *__restrict__ rmax_rmin,
                                                int64_t *__restrict__ argmax_argmin, Extreme2 *wmax, Extreme2 *wmin,
                                                double *wthr /* 2 * 16 doubles */, bool edges_uniform, bool have_reach,
-                                               const double reach[2])
+                                               const double reach[2], Also &&also = Also{})
 {
     using mask_t = unsigned long long;
     const double e0 = H > 0 ? lds_dyn[base] : 0.0, eH = H > 0 ? lds_dyn[base + H] : 0.0;
@@ -904,6 +916,7 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
         for (int u = 0; u < U; u++) {
             const int32_t i = i0 + u * View::STRIDE;
             exact_point(px[u], py[u], i, !check || i < P.n, H > 0);
+            also.any(px[u], py[u], i, !check || i < P.n);
         }
     };
 
@@ -965,6 +978,7 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
                 const double dx = px[u] - cx, dy = py[u] - cy;
                 const double d2 = fma(dx, dx, dy * dy);
                 const double r1 = d2 * rsqrt_nr(d2);
+                also.quick(dx, dy, r1, u);
                 // (negated compares: a NaN radius - a point on the centre, an overflow - goes to the exact code)
                 mask_t o = __builtin_amdgcn_ballot_w64(!(r1 < t_hi)) | __builtin_amdgcn_ballot_w64(!(r1 > t_lo));
                 if constexpr (HIST) {
@@ -979,6 +993,7 @@ __device__ __forceinline__ void residual_slice(const View &P, double cx, double 
                 odd[u] = o;
                 any |= o;
             }
+            also.quick_done(i0, View::STRIDE);
             if (any) {
 #pragma unroll
                 for (int u = 0; u < U; u++)
@@ -1302,6 +1317,98 @@ int launch_residual_stats(const double *x, const double *y, const int64_t *offse
     return PCFIT_OK;
 }
 
+// boundary_by_angle_max (boundary.py:7-42) and the residual statistics (gui.py:972-987, analyzer.py:83-92) about
+// the same circle in ONE sweep over the slice: both start from a point's offsets from the centre and its quick
+// radius, and a slice of a scan-sized window is far too long to stay on chip between two kernels.  The streamed
+// shape of the residual pass (loads of two trips in flight) with the angular bins of angle_math.h riding along.
+// Dynamic LDS: (H+1) doubles of edges, the histogram counters, then angle_bins_lds_bytes(bins).
+struct BoundaryAlso {
+    AngleBins *ab;
+    AngleBins::Probe pr[4];
+    __device__ __forceinline__ void quick(double dx, double dy, double r1, int u) { pr[u] = ab->probe(dx, dy, r1, true); }
+    __device__ __forceinline__ void quick_done(int32_t i0, int32_t stride)
+    {
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            ab->settle(pr[u], (uint32_t)(i0 + u * stride), true);
+    }
+    __device__ __forceinline__ void any(double px, double py, int32_t i, bool valid) const
+    {
+        const double dx = px - ab->cx, dy = py - ab->cy;
+        const double d2 = fma(dx, dx, dy * dy);
+        ab->point(dx, dy, d2 * rsqrt_nr(d2), (uint32_t)i, valid);
+    }
+};
+
+__host__ __device__ inline size_t hist_lds_bytes(int32_t H)
+{
+    return H > 0 ? (size_t)(H + 1) * 8 + (((size_t)hist_copies(H) * hist_stride(H) * 4 + 7) & ~(size_t)7) : 0;
+}
+
+__global__ __launch_bounds__(256, 3) void boundary_residual_kernel(
+    const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets,
+    const double *__restrict__ cxcyr, int32_t bins, int64_t *__restrict__ sel, int32_t H,
+    const double *__restrict__ edges, int64_t *__restrict__ hist, double *__restrict__ rmax_rmin,
+    int64_t *__restrict__ argmax_argmin)
+{
+    __shared__ Extreme2 wmax[16], wmin[16];
+    __shared__ double wthr[2 * 16];
+    __shared__ int edges_off;
+    constexpr int BLOCK = 256;
+    const int64_t s = blockIdx.x;
+    const int64_t off = offsets[s], n = offsets[s + 1] - off;
+    const double cx = cxcyr[3 * s], cy = cxcyr[3 * s + 1], R = cxcyr[3 * s + 2];
+    if (threadIdx.x == 0)
+        edges_off = 0;
+    AngleBins ab;
+    ab.init(reinterpret_cast<char *>(lds_dyn) + hist_lds_bytes(H), bins, cx, cy);
+    if (H > 0)
+        for (int b = threadIdx.x; b < hist_copies(H) * hist_stride(H); b += BLOCK)
+            reinterpret_cast<int32_t *>(lds_dyn + H + 1)[b] = 0;
+    SliceView<0, 0, BLOCK> P;
+    P.load(x, y, off, n);
+    __syncthreads();
+    if (H > 0) {
+        const double e0 = edges[0], eH = edges[H];
+        const double width = (eH - e0) / (double)H, per_bin = (double)H / (eH - e0);
+        bool ok = true;
+        for (int b = threadIdx.x; b <= H; b += BLOCK) {
+            const double e = edges[b];
+            lds_dyn[b] = e;
+            ok &= fabs(e - fma((double)b, width, e0)) * per_bin <= 2.384185791015625e-07;
+        }
+        if (!ok)
+            edges_off = 1;
+    }
+    // the first stretch of the slice raises the angular bins' bounds only
+    {
+        const int32_t n_seed = P.n < ANGLE_SEED_POINTS ? P.n : ANGLE_SEED_POINTS;
+        for (int32_t i = threadIdx.x; i < n_seed; i += BLOCK) {
+            const double dx = P.xs[i] - cx, dy = P.ys[i] - cy;
+            const double d2 = fma(dx, dx, dy * dy);
+            ab.seed(dx, dy, d2 * rsqrt_nr(d2));
+        }
+    }
+    __syncthreads();
+    const double reach[2] = {0.0, 0.0};
+    residual_slice(P, cx, cy, R, H, 0, s, hist, rmax_rmin, argmax_argmin, wmax, wmin, wthr, edges_off == 0, false, reach,
+                   BoundaryAlso{&ab, {}});
+    ab.finish(P.xs, P.ys, P.n, sel + s * bins);
+}
+
+int launch_boundary_residual(const double *x, const double *y, const int64_t *offsets, int64_t S, const double *cxcyr,
+                             int32_t bins, int64_t *sel, int32_t H, const double *edges, int64_t *hist, double *rmm,
+                             int64_t *amm, hipStream_t st)
+{
+    if (S == 0) return PCFIT_OK;
+    const size_t lds = hist_lds_bytes(H) + angle_bins_lds_bytes(bins);
+    PCFIT_TRY(allow_lds(boundary_residual_kernel, lds));
+    boundary_residual_kernel<<<dim3((unsigned)S), dim3(256), lds, st>>>(x, y, offsets, cxcyr, bins, sel, H, edges, hist,
+                                                                     rmm, amm);
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
 }  // namespace pcfit
 
 using namespace pcfit;
@@ -1358,6 +1465,23 @@ PCFIT_API int pcfit_fit_residuals_batch_dev(const double *x, const double *y, co
     LmParams prm{huber_delta, lm_lambda0, tol_update, tol_cost, max_iter};
     return launch_fit_residual(x, y, offsets, n_slices, max_slice_len, prm, kasa_out, out, iters, status, n_bins,
                                edges, hist, rmax_rmin, argmax_argmin, as_stream(stream));
+}
+
+PCFIT_API int pcfit_boundary_residuals_batch_dev(const double *x, const double *y, const int64_t *offsets,
+                                                 int64_t n_slices, const double *cxcyr, int32_t bins, int64_t *sel,
+                                                 int32_t n_bins, const double *edges, int64_t *hist,
+                                                 double *rmax_rmin, int64_t *argmax_argmin, void *stream)
+{
+    PCFIT_ENTER();
+    PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31), "boundary_residuals: n_slices out of range");
+    PCFIT_REQUIRE(bins >= 1 && bins <= ANGLE_FAST_BINS, "boundary_residuals: bins must be 1..4096");
+    PCFIT_REQUIRE(n_bins >= 0 && n_bins <= 4096, "boundary_residuals: n_bins must be 0..4096");
+    if (n_slices == 0)
+        return PCFIT_OK;
+    PCFIT_REQUIRE(x && y && offsets && cxcyr && sel && rmax_rmin && argmax_argmin, "boundary_residuals: null pointer");
+    PCFIT_REQUIRE(n_bins == 0 || (edges && hist), "boundary_residuals: histogram asked for without edges/hist");
+    return launch_boundary_residual(x, y, offsets, n_slices, cxcyr, bins, sel, n_bins, edges, hist, rmax_rmin,
+                                    argmax_argmin, as_stream(stream));
 }
 
 #ifdef PCFIT_PHASE_CLOCK

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 
 #include "pcfit_internal.h"
+#include "angle_math.h"
 
 namespace pcfit {
 
@@ -115,38 +116,6 @@ __global__ __launch_bounds__(RES_BLOCK) void residuals_kernel(
     }
 }
 
-// the two exact passes of the angular-bin boundary over the points of one slice: largest radius per bin (r >= 0,
-// so its bit pattern orders like r; +1 keeps an all-zero radius apart from "empty"), then the first index that
-// attains it
-__device__ __forceinline__ int32_t exact_bin(double dx, double dy, double width, int32_t bins)
-{
-    const double fb = floor(wrap_angle(dy, dx) / width);
-    return fb < 0.0 ? 0 : (fb > (double)(bins - 1) ? bins - 1 : (int32_t)fb);
-}
-
-__device__ void angle_max_exact_passes(const double *__restrict__ x, const double *__restrict__ y, int64_t n,
-                                       double cx, double cy, double width, int32_t bins, unsigned long long *best,
-                                       unsigned int *who)
-{
-    for (int64_t i = threadIdx.x; i < n; i += RES_BLOCK) {
-        const double dx = x[i] - cx, dy = y[i] - cy;
-        const double r = cr_hypot(dx, dy);
-        if (r == r && dx == dx && dy == dy)
-            atomicMax(&best[exact_bin(dx, dy, width, bins)], (unsigned long long)__double_as_longlong(r) + 1ull);
-    }
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < n; i += RES_BLOCK) {
-        const double dx = x[i] - cx, dy = y[i] - cy;
-        const double r = cr_hypot(dx, dy);
-        if (r == r && dx == dx && dy == dy) {
-            const int32_t b = exact_bin(dx, dy, width, bins);
-            if ((unsigned long long)__double_as_longlong(r) + 1ull == best[b])
-                atomicMin(&who[b], (unsigned int)i);
-        }
-    }
-    __syncthreads();
-}
-
 // dynamic LDS: bins uint64 (bit pattern of the largest radius) + bins int32 (index)
 __global__ __launch_bounds__(RES_BLOCK) void angle_max_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets,
@@ -169,156 +138,64 @@ __global__ __launch_bounds__(RES_BLOCK) void angle_max_kernel(
         sel[s * bins + b] = who[b] == 0xffffffffu ? -1 : (int64_t)who[b];
 }
 
-// The angle of (dx, dy) in [0, 2 pi) to within ANGLE_EPS of what wrap_angle gives: atan(a) = a P(a^2) on [0, 1]
-// (least-squares fit of degree 9 in a^2, largest error 1.03e-9 over two million samples), the octant by selects.
-// Not a number when both are zero.
-constexpr double ANGLE_EPS = 4e-9;
-__device__ __forceinline__ double quick_angle(double dx, double dy)
-{
-    const double ax = fabs(dx), ay = fabs(dy);
-    const double big = fmax(ax, ay), small = fmin(ax, ay);
-    double inv = __builtin_amdgcn_rcp(big);
-    inv = fma(fma(-big, inv, 1.0), inv, inv);
-    const double a = small * inv, t = a * a;
-    double p = -0.0014725780479088223;
-    p = fma(p, t, 0.0093928847604004759);
-    p = fma(p, t, -0.028141839582183099);
-    p = fma(p, t, 0.054646419595965126);
-    p = fma(p, t, -0.081889499675001379);
-    p = fma(p, t, 0.10868261333087868);
-    p = fma(p, t, -0.14244972689331231);
-    p = fma(p, t, 0.19996155516714859);
-    p = fma(p, t, -0.33333164390779585);
-    p = fma(p, t, 0.9999999778952402);
-    double th = a * p;
-    th = ay > ax ? 0.25 * TWO_PI - th : th;
-    th = dx < 0.0 ? 0.5 * TWO_PI - th : th;
-    th = dy < 0.0 ? TWO_PI - th : th;
-    return th;
-}
-
-// boundary_by_angle_max for up to ANGLE_FAST_BINS bins without a hypot and an atan2 per point.  Pass 1 takes the
-// radius from the reciprocal square root (within 4.7e-16) and the bin from quick_angle; a point whose quick angle
-// comes within ANGLE_EPS of a bin's edge is left out here, every other point is in the bin it is counted in, so the
-// largest quick radius of a bin (kept as a float rounded down) is a lower bound of the bin's largest radius.  Pass 2
-// finds the candidates - the points left out, and those whose quick radius reaches their bin's bound - and lists
-// them (one or two per bin); the exact code (correctly rounded hypot, atan2, numpy's bin rule) then runs over the
-// list twice: largest radius per bin, first index that attains it.  A point that attains its bin's largest radius
-// is always on the list, and everything on the list is judged exactly, so the result is that of the exact passes
-// over all points.  A list that overflows (it cannot with distinct radii) sends the slice through those passes.
-// Dynamic LDS: bins x (uint64 best, uint32 who, uint32 bound) + (2 bins + 256) x uint32 list.
-constexpr int ANGLE_FAST_BINS = 4096;
+// boundary_by_angle_max in one sweep (AngleBins, angle_math.h).  Dynamic LDS: angle_bins_lds_bytes(bins).
 __global__ __launch_bounds__(RES_BLOCK) void angle_max_fast_kernel(
     const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ offsets,
     const double *__restrict__ cxcyr, int32_t bins, int64_t *__restrict__ sel)
 {
     extern __shared__ double lds_raw[];
-    __shared__ unsigned int n_list;
-    unsigned long long *best = reinterpret_cast<unsigned long long *>(lds_raw);
-    unsigned int *who = reinterpret_cast<unsigned int *>(best + bins);
-    unsigned int *bound = who + bins;
-    unsigned int *list = bound + bins;
-    const unsigned int cap = 2u * (unsigned int)bins + 256u;
     const int64_t s = blockIdx.x;
     const int64_t off = offsets[s], n = offsets[s + 1] - off;
     const double *xs = x + off, *ys = y + off;
     const double cx = cxcyr[3 * s], cy = cxcyr[3 * s + 1];
-    const double width = TWO_PI / (double)bins, inv_width = (double)bins / TWO_PI;
-    const double margin = ANGLE_EPS * inv_width + 1e-9;                  // in bins
-    for (int b = threadIdx.x; b < bins; b += RES_BLOCK) {
-        best[b] = 0ull;
-        who[b] = 0xffffffffu;
-        bound[b] = 0u;
-    }
-    if (threadIdx.x == 0)
-        n_list = 0u;
+    AngleBins ab;
+    ab.init(lds_raw, bins, cx, cy);
     __syncthreads();
     constexpr int U = 4;
-    // quick radius and bin of point i; clear: the bin is certain.  (Negated compares: a NaN is not clear.)
-    auto quick = [&](double px, double py, double &r1, int32_t &b) -> bool {
-        const double dx = px - cx, dy = py - cy;
+    auto quick = [&](double px, double py, double &dx, double &dy) {
+        dx = px - cx;
+        dy = py - cy;
         const double d2 = fma(dx, dx, dy * dy);
-        r1 = d2 * rsqrt_nr(d2);
-        const double tb = quick_angle(dx, dy) * inv_width;
-        const double fb = floor(tb);
-        const bool clear = fabs((tb - fb) - 0.5) < 0.5 - margin && fb >= 0.0 && fb < (double)bins && r1 == r1;
-        b = clear ? (int32_t)fb : 0;
-        return clear;
+        return d2 * rsqrt_nr(d2);
     };
-    const int64_t full = n / (U * RES_BLOCK) * (U * RES_BLOCK);
-    // pass 1
-    for (int64_t base = threadIdx.x; base < n; base += U * RES_BLOCK) {
+    // (a slice of 2^31 points or more - none of the reference's scans comes near - takes the exact passes)
+    if (n >= (1ll << 31)) {
+        angle_max_exact_passes(xs, ys, n, cx, cy, ab.width, bins, ab.best, ab.who);
+        for (int b = threadIdx.x; b < bins; b += RES_BLOCK)
+            sel[s * bins + b] = ab.who[b] == 0xffffffffu ? -1 : (int64_t)ab.who[b];
+        return;
+    }
+    const uint32_t n32 = (uint32_t)n;
+    // the first stretch raises bounds only
+    const uint32_t n_seed = n32 < ANGLE_SEED_POINTS ? n32 : ANGLE_SEED_POINTS;
+    for (uint32_t i = threadIdx.x; i < n_seed; i += RES_BLOCK) {
+        double dx, dy;
+        const double r1 = quick(xs[i], ys[i], dx, dy);
+        ab.seed(dx, dy, r1);
+    }
+    __syncthreads();
+    // (uniform trip count; the loads of a trip are issued together, past the end they read the last point again)
+    const uint32_t last = n32 ? n32 - 1 : 0;
+    for (uint32_t base = threadIdx.x; base - threadIdx.x < n32; base += U * RES_BLOCK) {
         double px[U], py[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int64_t i = base + u * RES_BLOCK;
-            const int64_t ic = i < n ? i : n - 1;
-            px[u] = xs[ic];
-            py[u] = ys[ic];
+            const uint32_t i = base + u * RES_BLOCK;
+            px[u] = xs[i < last ? i : last];
+            py[u] = ys[i < last ? i : last];
         }
+        AngleBins::Probe pr[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            double r1;
-            int32_t b;
-            const bool clear = quick(px[u], py[u], r1, b);
-            if (clear && (base < full || base + u * RES_BLOCK < n))
-                atomicMax(&bound[b], __float_as_uint(__double2float_rd(r1)) + 1u);
-        }
-    }
-    __syncthreads();
-    // pass 2
-    for (int64_t base = threadIdx.x; base < n; base += U * RES_BLOCK) {
-        double px[U], py[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int64_t i = base + u * RES_BLOCK;
-            const int64_t ic = i < n ? i : n - 1;
-            px[u] = xs[ic];
-            py[u] = ys[ic];
+            double dx, dy;
+            const double r1 = quick(px[u], py[u], dx, dy);
+            pr[u] = ab.probe(dx, dy, r1, base + u * RES_BLOCK < n32);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            double r1;
-            int32_t b;
-            const bool clear = quick(px[u], py[u], r1, b);
-            const unsigned int k = bound[b];
-            // (bound - 1 is the float's bit pattern; an empty bin has no clear point, so nobody asks)
-            const double thr = (double)__uint_as_float(k - 1u) * (1.0 - 2e-15);
-            const bool cand = (!clear || !(r1 < thr)) && (base < full || base + u * RES_BLOCK < n);
-            if (cand) {
-                const unsigned int at = atomicAdd(&n_list, 1u);
-                if (at < cap)
-                    list[at] = (unsigned int)(base + u * RES_BLOCK);
-            }
-        }
+        for (int u = 0; u < U; u++)
+            ab.settle(pr[u], base + u * RES_BLOCK, base + u * RES_BLOCK < n32);
     }
-    __syncthreads();
-    const unsigned int listed = n_list;
-    if (listed > cap) {
-        angle_max_exact_passes(xs, ys, n, cx, cy, width, bins, best, who);
-    } else {
-        for (unsigned int k = threadIdx.x; k < listed; k += RES_BLOCK) {
-            const unsigned int i = list[k];
-            const double dx = xs[i] - cx, dy = ys[i] - cy;
-            const double r = cr_hypot(dx, dy);
-            if (r == r && dx == dx && dy == dy)
-                atomicMax(&best[exact_bin(dx, dy, width, bins)], (unsigned long long)__double_as_longlong(r) + 1ull);
-        }
-        __syncthreads();
-        for (unsigned int k = threadIdx.x; k < listed; k += RES_BLOCK) {
-            const unsigned int i = list[k];
-            const double dx = xs[i] - cx, dy = ys[i] - cy;
-            const double r = cr_hypot(dx, dy);
-            if (r == r && dx == dx && dy == dy) {
-                const int32_t b = exact_bin(dx, dy, width, bins);
-                if ((unsigned long long)__double_as_longlong(r) + 1ull == best[b])
-                    atomicMin(&who[b], i);
-            }
-        }
-        __syncthreads();
-    }
-    for (int b = threadIdx.x; b < bins; b += RES_BLOCK)
-        sel[s * bins + b] = who[b] == 0xffffffffu ? -1 : (int64_t)who[b];
+    ab.finish(xs, ys, n, sel + s * bins);
 }
 
 }  // namespace pcfit
@@ -368,7 +245,7 @@ PCFIT_API int pcfit_angle_max_batch_dev(const double *x, const double *y, const 
     // (read at every call so that a test can compare the two kernels)
     const char *env = getenv("PCFIT_ANGLE_MAX_EXACT");
     if (bins <= ANGLE_FAST_BINS && !(env && atoi(env))) {
-        const size_t lds = (size_t)bins * 16 + ((size_t)2 * bins + 256) * 4;
+        const size_t lds = angle_bins_lds_bytes(bins);
         if (lds > 48 * 1024)
             PCFIT_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&angle_max_fast_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

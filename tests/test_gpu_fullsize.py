@@ -77,6 +77,11 @@ def test_hundred_million_points_in_two_thousand_windows():
     sel = F.angle_max_batch(x, y, off, fit, bins=720)
     res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
     assert np.all(st == 0) and res["hist"].sum() <= off[-1]
+    # boundary and statistics from ONE read of every window: the same indices, counts and extremes
+    both = F.boundary_residuals_batch(x, y, off, fit, bins=720, hist_bins=256, lo=-0.5, hi=0.5)
+    assert np.array_equal(both["sel"], sel) and np.array_equal(both["hist"], res["hist"])
+    for k in ("argmax", "argmin", "rmax", "rmin"):
+        assert np.array_equal(both[k], res[k]), k
     for s in (0, 611, 1370, 1999):
         m = R.slice_members(z, lo[s], hi[s])
         assert off[s + 1] - off[s] == m.size

@@ -1273,6 +1273,61 @@ def test_one_million_point_scan_through_the_analyzer():
         assert abs(got["k2_amp"] - want["k2_amp"]) < 1e-12
 
 
+def test_boundary_and_residual_statistics_in_one_sweep():
+    """pcfit_boundary_residuals_batch: the angular-bin boundary and the residual statistics of every slice from one
+    read of it.  Indices, counts and extremes equal those of the two separate calls (their exact kernels) and of the
+    C restatement - slice lengths around the kernel's shape boundaries, rings, outliers, open arcs (empty bins),
+    duplicates and a lattice (equal radii: the first index wins), a slice a million units from the origin, points in
+    ascending order of radius (every point a record breaker: the candidate list overflows and the exact passes
+    take over), a point on the centre, NaN coordinates."""
+    gen = np.random.default_rng(515)
+    sets = []
+    for n in (0, 1, 2, 3, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8193, 20001, 50000):
+        kind = ["ring", "outliers", "arc", "dups", "far"][len(sets) % 5]
+        th = gen.uniform(0, 1.1 * np.pi if kind == "arc" else 2 * np.pi, n)
+        rr = 10.0 + gen.normal(0, 0.05, n)
+        if kind == "outliers":
+            bad = gen.random(n) < 0.2
+            rr[bad] = gen.uniform(0, 14.0, int(bad.sum()))
+        c = np.array([1e6, -2e6]) if kind == "far" else np.array([3.0, -2.0])
+        xy = c + np.stack([rr * np.cos(th), rr * np.sin(th)], 1)
+        if kind == "dups" and n > 4:
+            xy[n // 2:] = xy[: n - n // 2]
+        sets.append((xy, c))
+    gx, gy = np.meshgrid(np.arange(-20.0, 21.0), np.arange(-20.0, 21.0))
+    sets.append((np.stack([gx.ravel(), gy.ravel()], 1), np.array([0.0, 0.0])))          # lattice: ties, a point on the centre
+    th = np.linspace(0, 40 * np.pi, 30000)
+    sets.append((np.stack([(5 + th / 30) * np.cos(th), (5 + th / 30) * np.sin(th)], 1), np.array([0.0, 0.0])))   # spiral outwards
+    bad = sets[3][0].copy()
+    sets.append((np.concatenate([bad, [[np.nan, 1.0], [2.0, np.nan]]]), np.array([3.0, -2.0])))
+    x, y, off = csr([a for a, _ in sets])
+    fit = np.array([[c[0] + 0.01, c[1] - 0.02, 10.0] for _, c in sets])
+    for bins, H, lo, hi in ((720, 256, -0.5, 0.5), (90, 64, -12.0, 25.0), (4096, 0, 0.0, 1.0), (1, 7, -0.2, 0.2)):
+        both = F.boundary_residuals_batch(x, y, off, fit, bins=bins, hist_bins=H, lo=lo, hi=hi)
+        os.environ["PCFIT_ANGLE_MAX_EXACT"] = "1"
+        os.environ["PCFIT_RESIDUALS_EXACT"] = "1"
+        try:
+            sel = F.angle_max_batch(x, y, off, fit, bins=bins)
+            res = F.residuals_batch(x, y, off, fit, bins=H, lo=lo, hi=hi, want_theta=False, want_dr=False)
+        finally:
+            del os.environ["PCFIT_ANGLE_MAX_EXACT"], os.environ["PCFIT_RESIDUALS_EXACT"]
+        assert np.array_equal(both["sel"], sel), bins
+        if H:
+            assert np.array_equal(both["hist"], res["hist"]), H
+        for k in ("argmax", "argmin", "rmax", "rmin"):
+            assert np.array_equal(both[k], res[k]), k
+        for s in (3, 9, 13, len(sets) - 3, len(sets) - 2):
+            xy = sets[s][0]
+            assert np.array_equal(N.angle_max(xy, fit[s][0], fit[s][1], bins), both["sel"][s]), (bins, s)
+            if H:
+                o = N.residuals(xy, *fit[s], bins=H, lo=lo, hi=hi, per_point=False)
+                assert np.array_equal(o["hist"], both["hist"][s]), (H, s)
+                assert (o["argmax"], o["argmin"]) == (both["argmax"][s], both["argmin"][s])
+    # the boundary alone takes the same single sweep
+    assert np.array_equal(F.angle_max_batch(x, y, off, fit, bins=720),
+                          F.boundary_residuals_batch(x, y, off, fit, bins=720)["sel"])
+
+
 def test_scan_sized_boundary_and_histogram_pass():
     """20 M points in 400 windows (50 000 per window): binning, Kasa + LM from global memory, angular-bin
     boundary and residual histograms; eight windows replayed on the CPU."""
@@ -1285,6 +1340,9 @@ def test_scan_sized_boundary_and_histogram_pass():
     fit, iters = F.lm_batch(x, y, off, kasa)
     sel = F.angle_max_batch(x, y, off, fit, bins=720)
     res = F.residuals_batch(x, y, off, fit, bins=256, lo=-0.5, hi=0.5, want_theta=False, want_dr=False)
+    both = F.boundary_residuals_batch(x, y, off, fit, bins=720, hist_bins=256, lo=-0.5, hi=0.5)    # one read of every window
+    assert np.array_equal(both["sel"], sel) and np.array_equal(both["hist"], res["hist"])
+    assert np.array_equal(both["argmax"], res["argmax"]) and np.array_equal(both["rmin"], res["rmin"])
     assert off[-1] == np.count_nonzero((z >= lo[0]) & (z <= hi[-1])) + np.count_nonzero(np.isin(z, lo[1:]))
     for s in np.random.default_rng(2).choice(S, 8, replace=False):
         m = R.slice_members(z, lo[s], hi[s])
