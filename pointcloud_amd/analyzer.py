@@ -158,16 +158,18 @@ class CylinderAnalyzer:
             save_results(results, frames, ".")
         return results
 
-    def _analyze_windows(self, points, z_centers, want_edges=False):
-        """Yield (result, edge columns or None, warning) per window, in window order."""
-        if len(z_centers) == 0:
-            return
+    def _hybrid_windows(self, points, z_centers):
+        """The hybrid fit and the metrics of every window of a scan (an (N,3) array or a DeviceScan), as the dict
+        of arrays _ffi.scan_hybrid_batch returns: the scan is uploaded once (if it is not resident already) and
+        binned on the device; only per-window results come back."""
         dz = self.config.z_step / 2.0
         z_centers = np.asarray(z_centers, float)
-        # the scan is uploaded once and binned on the device; only per-window results come back
-        h = _ffi.scan_hybrid_batch(points, z_centers - dz, z_centers + dz, _FIT["inlier_tol"], _FIT["max_trials"],
-                                   _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"],
-                                   order=self.config.hull_order)
+        return _ffi.scan_hybrid_batch(points, z_centers - dz, z_centers + dz, _FIT["inlier_tol"], _FIT["max_trials"],
+                                      _FIT["min_inliers_frac"], None, _FIT["huber_delta"], _FIT["use_hull"],
+                                      order=self.config.hull_order)
+
+    def _results_of(self, z_centers, h, want_edges=False):
+        """(result, edge columns or None, warning) per window, in window order, from the arrays of _hybrid_windows."""
         # Building hundreds of thousands of small lists and dicts makes the cyclic garbage collector walk them
         # again and again (a 4x slowdown measured on the candidate lists alone); it is paused while the
         # results are put together, and they are handed out afterwards.
@@ -176,11 +178,16 @@ class CylinderAnalyzer:
         was_enabled = gc.isenabled()
         gc.disable()
         try:
-            out = list(self._window_results(z_centers, h, want_edges))
+            return list(self._window_results(np.asarray(z_centers, float), h, want_edges))
         finally:
             if was_enabled:
                 gc.enable()
-        yield from out
+
+    def _analyze_windows(self, points, z_centers, want_edges=False):
+        """Yield (result, edge columns or None, warning) per window, in window order."""
+        if len(z_centers) == 0:
+            return
+        yield from self._results_of(z_centers, self._hybrid_windows(points, z_centers), want_edges)
 
     def _window_results(self, z_centers, h, want_edges):
         dz = self.config.z_step / 2.0
@@ -242,29 +249,36 @@ class CylinderAnalyzer:
                 }
             yield result, edge, None
 
-    def analyze_with_progress(self, points: np.ndarray, progress_callback=None):
-        """Analyze points with progress reporting (reference: analyzer.py:181-230).
-        All windows run in one GPU batch; the callback then receives the same
-        integer percentages the reference's thread pool would emit."""
+    def _resident(self, points):
+        """The scan on the GPU, as analyze_with_progress takes it (reference: analyzer.py:185-196): an (N,3) array
+        goes up once - with Config.z_min / z_max only its rows inside that closed range, in their order, picked
+        by the library's host threads while they stage the upload (no masked copy of the scan on the host) - and
+        a DeviceScan passes through."""
         if isinstance(points, _ffi.DeviceScan):
             # a scan already on the GPU; a configured z range would have to filter it, which needs the array
             if self.z_min is not None and self.z_max is not None:
                 raise ValueError("a DeviceScan cannot be combined with Config.z_min / z_max: pass the array")
-        else:
-            if not isinstance(points, np.ndarray):
-                points = np.array(points)
+            return points
+        if not isinstance(points, np.ndarray):
+            points = np.array(points)
 
-            if points.ndim != 2 or points.shape[1] != 3:
-                raise ValueError("Points must be Nx3 array")
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("Points must be Nx3 array")
 
-            if self.z_min is not None and self.z_max is not None:
-                mask = (points[:, 2] >= self.z_min) & (points[:, 2] <= self.z_max)
-                points = points[mask]
-                if len(points) == 0:
-                    raise ValueError(f"No points in specified Z range [{self.z_min}, {self.z_max}]")
-            elif len(points) > 0:
-                # upload once; the z range comes back from the device instead of two strided host passes
-                points = _ffi.DeviceScan(points)
+        if self.z_min is not None and self.z_max is not None:
+            points = _ffi.DeviceScan(points, z_range=(self.z_min, self.z_max))
+            if len(points) == 0:
+                raise ValueError(f"No points in specified Z range [{self.z_min}, {self.z_max}]")
+        elif len(points) > 0:
+            # upload once; the z range comes back from the device instead of two strided host passes
+            points = _ffi.DeviceScan(points)
+        return points
+
+    def analyze_with_progress(self, points: np.ndarray, progress_callback=None):
+        """Analyze points with progress reporting (reference: analyzer.py:181-230).
+        All windows run in one GPU batch; the callback then receives the same
+        integer percentages the reference's thread pool would emit."""
+        points = self._resident(points)
 
         results = []
         z_centers = self.calculate_z_centers(points)

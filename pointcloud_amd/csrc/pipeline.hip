@@ -550,7 +550,7 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
 static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
                                    const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total,
                                    const double *px, const double *py, const double *dux, const double *duy,
-                                   const int64_t *doff, int64_t *dnh, int64_t *dhi, hipStream_t st)
+                                   const int64_t *doff, int64_t *dnh, int64_t *dhi, hipStream_t st, int64_t max_hull)
 {
     bool any = false;
     for (int64_t s = 0; hull_start && s < S && !any; s++) any = hull_start[s] == PCFIT_HULL_START_QHULL;
@@ -565,7 +565,7 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
     if (!on_host) {
         PCFIT_TRY(dscratch.alloc((size_t)total * 8));
         PCFIT_TRY(qhull_start_dev(px, py, doff, d_n_pts, dnh, d_hull_start, S, total, dscratch.as<int>(),
-                                  dstart.as<int64_t>(), dxy.as<double>(), st));
+                                  dstart.as<int64_t>(), dxy.as<double>(), st, max_hull));
         PCFIT_TRY(dstart.download(start.data(), (size_t)S * 8, st));
         PCFIT_HIP(hipStreamSynchronize(st));
     } else {
@@ -631,11 +631,11 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
 static int apply_qhull_starts(const int64_t *hull_start, const int64_t *d_hull_start, const int64_t *offsets,
                               const int64_t *n_pts, const int64_t *d_n_pts, int64_t S, int64_t total, const double *px,
                               const double *py, const double *dux, const double *duy, const int64_t *doff,
-                              int64_t *dnh, int64_t *dhi, hipStream_t st)
+                              int64_t *dnh, int64_t *dhi, hipStream_t st, int64_t max_hull = -1)
 {
     try {
         return apply_qhull_starts_impl(hull_start, d_hull_start, offsets, n_pts, d_n_pts, S, total, px, py, dux, duy,
-                                       doff, dnh, dhi, st);
+                                       doff, dnh, dhi, st, max_hull);
     } catch (const std::exception &e) {
         (void)hipStreamSynchronize(st);                // nothing of this call may still be copying into freed vectors
         set_error("qhull order: %s", e.what());
@@ -842,15 +842,16 @@ static int hybrid_core_impl(const double *dxp, const double *dyp, const int64_t 
     memcpy(n_unique, hbuf.data() + nu_at, (size_t)S * 8);
     memcpy(n_hull.data(), hbuf.data() + nh_at, (size_t)S * 8);
     memcpy(status, hbuf.data() + st1_at, (size_t)S * 4);
+    const int64_t max_hull = S ? *std::max_element(n_hull.begin(), n_hull.end()) : 0;
     if (use_hull && qhull_raw) {
         std::vector<int64_t> lens((size_t)S);
         for (int64_t s = 0; s < S; s++) lens[(size_t)s] = offsets[s + 1] - offsets[s];
         PCFIT_TRY(apply_qhull_starts(qhull_everywhere.data(), nullptr, offsets, lens.data(), nullptr, S, total, dxp, dyp,
-                                     dux.as<double>(), duy.as<double>(), doffp, dnh, dhi.as<int64_t>(), st));
+                                     dux.as<double>(), duy.as<double>(), doffp, dnh, dhi.as<int64_t>(), st, max_hull));
     } else if (use_hull)
         PCFIT_TRY(apply_qhull_starts(hull_start, dhs.as<int64_t>(), offsets, n_unique, dnu, S, total, dux.as<double>(),
                                      duy.as<double>(), dux.as<double>(), duy.as<double>(), doffp, dnh,
-                                     dhi.as<int64_t>(), st));
+                                     dhi.as<int64_t>(), st, max_hull));
     if (use_hull && (qhull_raw || hull_start)) {
         // (walks in Qhull's order are brought to Qhull's vertex set too: the counts may have gone down)
         PCFIT_HIP(hipMemcpyAsync(n_hull.data(), dnh, (size_t)S * 8, hipMemcpyDeviceToHost, st));

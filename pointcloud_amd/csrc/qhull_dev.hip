@@ -10,21 +10,49 @@
 // units above the first new facet, two facets get their first point through the horizon search in one
 // insertion - or one of the fixed capacities below runs out, or the replay ends with more vertices than
 // the exact hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
+#include <stdlib.h>
+
 #include "pcfit_internal.h"
 
 namespace pcfit {
 __device__ unsigned long long g_qhull_reason[16];      // slices handed back, by cause (tools and tests)
+// Optional phase timing (tools only; -DPCFIT_PHASE_CLOCK): thread 0 of one workgroup in 16 adds the clocks spent
+// between marks to g_qphase[k] (0 extremes, 1 simplex, 2 first partition, 3 placing, 4 the list's thread,
+// 5 partition of visible sets, 6 farthest points, 7 the end).
+#ifdef PCFIT_PHASE_CLOCK
+__device__ unsigned long long g_qphase[8];
+struct QPhase {
+    long long last;
+    __device__ __forceinline__ bool on() const { return threadIdx.x == 0 && (blockIdx.x & 15) == 0; }
+    __device__ __forceinline__ void init() { last = on() ? wall_clock64() : 0; }
+    __device__ __forceinline__ void mark(int k)
+    {
+        if (on()) {
+            const long long now = wall_clock64();
+            atomicAdd(&g_qphase[k], (unsigned long long)(now - last));
+            last = now;
+        }
+    }
+};
+#else
+struct QPhase {
+    __device__ __forceinline__ void init() {}
+    __device__ __forceinline__ void mark(int) {}
+};
+#endif
 namespace {
 
 constexpr int QT = 256;          // threads of a workgroup
-constexpr int QF = 480;          // live facets of a slice (slot 0 is the list's tail)
+constexpr int QF_MAX = 480;      // live facets of a slice (slot 0 is the list's tail): the kernel's roomiest form
 constexpr int QP = 5;            // pieces an outside set may lie in
 constexpr int QV = 6;            // visible facets of one insertion
 constexpr int QU = 32;           // points of one insertion that go through the horizon search
 constexpr int64_t QHULL_DEFER = QHULL_START_DEFER;
 constexpr unsigned IDX_MASK = 0x7fffffffu;      // a piece's start; the top bit names the buffer it lies in
 
+template <int QF>
 struct Shared {
+    static constexpr int FACETS = QF;
     double n0[QF], n1[QF], off[QF];
     double far_d[QF];
     int v0[QF], v1[QF], total[QF], far_idx[QF];
@@ -34,7 +62,7 @@ struct Shared {
     // one insertion
     int c0[QV * QP], c1[QV * QP];
     double wave_d[2][QT / 64];
-    int wave_i[2][QT / 64], wave_tie[2][QT / 64];
+    int wave_i[2][QT / 64], wave_tie[2][QT / 64], wave_flag[QT / 64];
     int vis[QV], nvis, newf[2], apex, state, reason, n_free, head, nextf;
     // points below both new facets by less than a roundoff unit: Qhull searches the horizon for them
     int unc_p[QU], unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
@@ -50,9 +78,11 @@ struct Shared {
     int ext[4];
 };
 
-__device__ inline double plane_dist(const Shared &S, int f, double x, double y) { return S.off[f] + x * S.n0[f] + y * S.n1[f]; }
+template <class SH>
+__device__ inline double plane_dist(const SH &S, int f, double x, double y) { return S.off[f] + x * S.n0[f] + y * S.n1[f]; }
 
-__device__ inline void set_plane(Shared &S, int f, const double *x, const double *y)
+template <class SH>
+__device__ inline void set_plane(SH &S, int f, const double *x, const double *y)
 {
     const int a = S.v0[f], b = S.v1[f];
     const double nx = y[b] - y[a], ny = x[a] - x[b];
@@ -64,13 +94,15 @@ __device__ inline void set_plane(Shared &S, int f, const double *x, const double
 }
 
 // qh_removefacet / qh_appendfacet on the list in LDS (one thread)
-__device__ inline void list_remove(Shared &S, int k)
+template <class SH>
+__device__ inline void list_remove(SH &S, int k)
 {
     if (S.nextf == k) S.nextf = S.next[k];
     if (S.head == k) { S.head = S.next[k]; S.prev[S.next[k]] = -1; }
     else { S.next[S.prev[k]] = S.next[k]; S.prev[S.next[k]] = S.prev[k]; }
 }
-__device__ inline void list_append(Shared &S, int k)
+template <class SH>
+__device__ inline void list_append(SH &S, int k)
 {
     if (S.nextf == 0) S.nextf = k;
     S.prev[k] = S.prev[0];
@@ -99,20 +131,32 @@ __device__ inline void key_take(Key &a, double k1, double k2, int at)
 {
     if (at >= 0 && (a.at < 0 || k1 < a.k1 || (k1 == a.k1 && k2 < a.k2))) { a.k1 = k1; a.k2 = k2; a.at = at; }
 }
-__device__ void block_extremes(Shared &S, const double *x, const double *y, int m, int out[4])
+template <int M>
+__device__ __forceinline__ void key_fold(Key &e, int lane)
+{
+    if constexpr (M >= 1) {
+        key_take(e, lane_xor<M>(e.k1, lane), lane_xor<M>(e.k2, lane), lane_xor_i32<M>(e.at, lane));
+        key_fold<M / 2>(e, lane);
+    }
+}
+template <class SH>
+__device__ void block_extremes(SH &S, const double *x, const double *y, int m, int out[4])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Key e[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) e[k] = {0.0, 0.0, -1};
-    for (int base = 0; base < m; base += QT * 4) {
-        double px[4], py[4];
+    // the loads of the next trip are in flight while this one is looked at (past the end they read the last point)
+    const int last = m - 1;
+    auto fetch = [&](double (&qx)[4], double (&qy)[4], int base) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = base + u * QT + tid;
-            px[u] = i < m ? x[i] : 0.0;
-            py[u] = i < m ? y[i] : 0.0;
+            qx[u] = x[i < last ? i : last];
+            qy[u] = y[i < last ? i : last];
         }
+    };
+    auto take = [&](const double (&px)[4], const double (&py)[4], int base) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int i = base + u * QT + tid, at = i < m ? i : -1;
@@ -121,11 +165,17 @@ __device__ void block_extremes(Shared &S, const double *x, const double *y, int 
             key_take(e[2], py[u], px[u], at);
             key_take(e[3], -py[u], px[u], at);
         }
+    };
+    double ax[4], ay[4], bx[4], by[4];
+    fetch(ax, ay, 0);
+    for (int base = 0; base < m; base += QT * 8) {
+        fetch(bx, by, base + QT * 4);
+        take(ax, ay, base);
+        fetch(ax, ay, base + QT * 8);
+        if (base + QT * 4 < m) take(bx, by, base + QT * 4);
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-        for (int d = 32; d >= 1; d >>= 1)
-            key_take(e[k], __shfl_xor(e[k].k1, d), __shfl_xor(e[k].k2, d), __shfl_xor(e[k].at, d));
+    for (int k = 0; k < 4; k++) key_fold<32>(e[k], lane);
     __syncthreads();
     if (lane == 0)
 #pragma unroll
@@ -140,27 +190,40 @@ __device__ void block_extremes(Shared &S, const double *x, const double *y, int 
 }
 
 // The farthest point of each of two classes, over what every thread has seen: (distance, point) per class in
-// far_d / far_i, and whether the greatest distance was met by more than one point.
-__device__ void block_far(Shared &S, const double *x, const double *y, double d0, int i0, double d1, int i1,
-                          double out_d[2], int out_i[2], int out_tie[2])
+// out_d / out_i, and whether the greatest distance was met by more than one point; `flag` comes back as the "or"
+// of every thread's.  One barrier: the partials of the last call were read before the barrier that every caller
+// passes between two calls.
+template <int M>
+__device__ __forceinline__ void far_fold(double &d, int &at, int &tie, const double *x, const double *y, int lane)
+{
+    if constexpr (M >= 1) {
+        const double od = lane_xor<M>(d, lane);
+        const int oi = lane_xor_i32<M>(at, lane), ot = lane_xor_i32<M>(tie, lane);
+        if (oi >= 0) {
+            if (at < 0 || od > d) { d = od; at = oi; tie = ot; }
+            else if (od == d && !same_point(x, y, oi, at)) tie = 1;
+        }
+        far_fold<M / 2>(d, at, tie, x, y, lane);
+    }
+}
+// t0, t1: this thread has met its own greatest distance at two different points already.
+template <class SH>
+__device__ void block_far(SH &S, const double *x, const double *y, double d0, int i0, int t0, double d1, int i1,
+                          int t1, double out_d[2], int out_i[2], int out_tie[2], bool &flag)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double d[2] = {d0, d1};
-    int at[2] = {i0, i1}, tie[2] = {0, 0};
-    for (int c = 0; c < 2; c++) {
-        for (int s = 32; s >= 1; s >>= 1) {
-            const double od = __shfl_xor(d[c], s);
-            const int oi = __shfl_xor(at[c], s), ot = __shfl_xor(tie[c], s);
-            if (oi >= 0) {
-                if (at[c] < 0 || od > d[c]) { d[c] = od; at[c] = oi; tie[c] = ot; }
-                else if (od == d[c] && !same_point(x, y, oi, at[c])) tie[c] = 1;
-            }
-        }
+    int at[2] = {i0, i1}, tie[2] = {t0, t1};
+    far_fold<32>(d[0], at[0], tie[0], x, y, lane);
+    far_fold<32>(d[1], at[1], tie[1], x, y, lane);
+    const bool wave_flag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
+    if (lane == 0) {
+        for (int c = 0; c < 2; c++) { S.wave_d[c][wave] = d[c]; S.wave_i[c][wave] = at[c]; S.wave_tie[c][wave] = tie[c]; }
+        S.wave_flag[wave] = wave_flag ? 1 : 0;
     }
     __syncthreads();
-    if (lane == 0)
-        for (int c = 0; c < 2; c++) { S.wave_d[c][wave] = d[c]; S.wave_i[c][wave] = at[c]; S.wave_tie[c][wave] = tie[c]; }
-    __syncthreads();
+    flag = false;
+    for (int w = 0; w < QT / 64; w++) flag = flag || S.wave_flag[w] != 0;
     for (int c = 0; c < 2; c++) {
         out_d[c] = 0.0;
         out_i[c] = -1;
@@ -175,20 +238,37 @@ __device__ void block_far(Shared &S, const double *x, const double *y, double d0
     }
 }
 
-// where a thread's point goes in its class's run: runs of class 0 grow upwards from `lo`, runs of class 1
-// downwards from the piece's end (one LDS atomic per wave and class)
-__device__ inline int wave_slot(int *counter, bool mine)
+// Where the points of one turn (U per thread) go in their class's run: one LDS atomic per wave and class for the
+// whole turn, its answer read by every lane from the lane that asked; slot[u] = the place of point u when it is of
+// that class.  (The order inside a run is not Qhull's and need not be.)
+template <int U>
+__device__ __forceinline__ void wave_slots(int *counter, const bool (&mine)[U], int (&slot)[U])
 {
-    const unsigned long long votes = __builtin_amdgcn_ballot_w64(mine);
-    if (!votes) return 0;
-    const int lane = threadIdx.x & 63, leader = __ffsll((long long)votes) - 1;
+    const int lane = threadIdx.x & 63;
+    unsigned long long votes[U];
+    int total = 0;
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        votes[u] = __builtin_amdgcn_ballot_w64(mine[u]);
+        total += __popcll(votes[u]);
+    }
     int base = 0;
-    if (lane == leader) base = atomicAdd(counter, __popcll(votes));
-    base = __shfl(base, leader);
-    return base + __popcll(votes & ((1ull << lane) - 1ull));
+    if (total) {                                        // (uniform over the wave)
+        if (lane == 0) base = atomicAdd(counter, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        slot[u] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(votes[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes[u], 0u));
+        base += __popcll(votes[u]);
+    }
 }
 
-__global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
+// QF: facet slots (the LDS a workgroup takes grows with them, and the workgroups a CU holds shrink: every phase of
+// this kernel waits - for memory, for the one thread that keeps the list - so it is the number of slices in
+// flight that fills the chip); WG: workgroups to a CU the registers are budgeted for.
+template <int QF, int WG>
+__global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
                                                          const int64_t *__restrict__ offsets,
                                                          const int64_t *__restrict__ n_unique,
                                                          const int64_t *__restrict__ n_hull,
@@ -196,7 +276,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                                                          int *__restrict__ buf_b, int64_t *__restrict__ start,
                                                          double *__restrict__ start_xy)
 {
-    __shared__ Shared S;
+    __shared__ Shared<QF> S;
     const int64_t s = blockIdx.x, off = offsets[s];
     const int tid = threadIdx.x;
     if (select && select[s] != PCFIT_HULL_START_QHULL) {
@@ -216,9 +296,17 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
     const double *x = ux + off, *y = uy + off;
     int *const bufs0 = buf_a + off, *const bufs1 = buf_b + off;
 
+    // (the free list and the visit marks: idle until the simplex is made, several barriers from here)
+    for (int k = tid; k < QF; k += QT) {
+        S.free_slot[k] = (short)(QF - 1 - k);       // slots QF-1 .. 1 (0 is the tail)
+        S.visit[k] = 0;
+    }
     // qh_maxmin, qh_detroundoff, qh_maxsimplex
+    QPhase ph;
+    ph.init();
     int ext4[4];
     block_extremes(S, x, y, m, ext4);
+    ph.mark(0);
     const int xlo = ext4[0], xhi = ext4[1], ylo = ext4[2], yhi = ext4[3];
     if (tid == 0) {
         S.state = 0;
@@ -311,10 +399,8 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         {
             const int minx = S.ext[0], maxx = S.ext[1], third = S.ext[2];
             // qh_createsimplex, qh_initialhull
-            for (int k = 0; k < QF; k++) S.free_slot[k] = (short)(QF - 1 - k);      // slots QF-1 .. 1 (0 is the tail)
             S.n_free = QF - 1;
             S.visit_id = 0;
-            for (int k = 0; k < QF; k++) S.visit[k] = 0;
             S.head = S.nextf = 0;
             S.prev[0] = -1;
             S.next[0] = 0;
@@ -355,6 +441,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
         return;
     }
+    ph.mark(1);
     // qh_partitionall: every point to the first of the three facets it lies outside of (counts, then places)
     {
         const int f0 = S.vis[0], f1 = S.vis[1], f2 = S.vis[2];
@@ -368,14 +455,19 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         // so that the placing pass below reads one byte a point instead of its coordinates
         unsigned char *cls = reinterpret_cast<unsigned char *>(bufs1);
         const double e0x = x[e0], e0y = y[e0], e1x = x[e1], e1y = y[e1], e2x = x[e2], e2y = y[e2];
-        for (int base = 0; base < m; base += QT * 4) {
-            double px[4], py[4];
+        // (the loads of the next turn are in flight while this one is classified; a wave counts its classes in
+        // scalar registers and adds them to the workgroup's once, at the end)
+        int n_of[3] = {0, 0, 0};
+        const int last = m - 1;
+        auto fetch = [&](double (&qx)[4], double (&qy)[4], int base) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = base + u * QT + tid;
-                px[u] = i < m ? x[i] : e0x;
-                py[u] = i < m ? y[i] : e0y;
+                qx[u] = x[i < last ? i : last];
+                qy[u] = y[i < last ? i : last];
             }
+        };
+        auto classify = [&](const double (&px)[4], const double (&py)[4], int base) {
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = base + u * QT + tid;
@@ -383,7 +475,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 double d = 0.0;
                 const bool vertex = (px[u] == e0x && py[u] == e0y) || (px[u] == e1x && py[u] == e1y) ||
                                     (px[u] == e2x && py[u] == e2y);
-                if (!vertex) {
+                if (!vertex && i < m) {
                     double most = -1e300;
                     int most_k = 3;
 #pragma unroll
@@ -400,29 +492,40 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 if (i < m) cls[i] = (unsigned char)c;
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const unsigned long long votes = __builtin_amdgcn_ballot_w64(c == k);
-                    if (votes && (tid & 63) == __ffsll((long long)votes) - 1) atomicAdd(&S.c0[k], __popcll(votes));
+                    n_of[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
                     if (c == k) {
                         if (fi[k] < 0 || d > fd[k]) { fd[k] = d; fi[k] = i; ft[k] = 0; }
                         else if (d == fd[k] && !same_point(x, y, i, fi[k])) ft[k] = 1;
                     }
                 }
             }
+        };
+        {
+            double ax[4], ay[4], bx[4], by[4];
+            fetch(ax, ay, 0);
+            for (int base = 0; base < m; base += QT * 8) {
+                fetch(bx, by, base + QT * 4);
+                classify(ax, ay, base);
+                fetch(ax, ay, base + QT * 8);
+                if (base + QT * 4 < m) classify(bx, by, base + QT * 4);
+            }
         }
+        if ((tid & 63) == 0)
+            for (int k = 0; k < 3; k++)
+                if (n_of[k]) atomicAdd(&S.c0[k], n_of[k]);
         if (doubt) { S.state = 2; S.reason = 3; }
         // the farthest point of each of the three sets
         double od[2];
         int oi[2], ot[2];
         double far_d[3];
         int far_i[3], far_t[3];
-        block_far(S, x, y, fd[0], fi[0], fd[1], fi[1], od, oi, ot);
+        bool none = false;
+        block_far(S, x, y, fd[0], fi[0], ft[0], fd[1], fi[1], ft[1], od, oi, ot, none);
         far_d[0] = od[0]; far_i[0] = oi[0]; far_t[0] = ot[0] | 0;
         far_d[1] = od[1]; far_i[1] = oi[1]; far_t[1] = ot[1];
-        block_far(S, x, y, fd[2], fi[2], 0.0, -1, od, oi, ot);
+        __syncthreads();                           // (the partials are read: they may be written again)
+        block_far(S, x, y, fd[2], fi[2], ft[2], 0.0, -1, 0, od, oi, ot, none);
         far_d[2] = od[0]; far_i[2] = oi[0]; far_t[2] = ot[0];
-        // private ties (one thread met the same distance twice)
-        for (int c = 0; c < 3; c++)
-            if (ft[c] && fi[c] >= 0 && fd[c] == far_d[c]) { S.state = 2; S.reason = 4; }
         __syncthreads();
         if (tid == 0) {
             const int cnt[3] = {S.c0[0], S.c0[1], S.c0[2]};
@@ -457,22 +560,38 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
             if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
             return;
         }
+        ph.mark(2);
         int *A = bufs0;
-        for (int base = 0; base < m; base += QT) {
-            const int i = base + tid;
-            const int c = i < m ? (int)cls[i] : 3;
+        const int run0 = S.c1[0], run1 = S.c1[1], run2 = S.c1[2];
+        for (int base = 0; base < m; base += QT * 4) {
+            int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + u * QT + tid;
+                c[u] = i < m ? (int)cls[i] : 3;
+            }
+#pragma unroll
             for (int k = 0; k < 3; k++) {
-                const int slot = wave_slot(&S.c0[k], c == k);
-                if (c == k) A[S.c1[k] + slot] = i;
+                bool mine[4];
+                int slot[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) mine[u] = c[u] == k;
+                wave_slots<4>(&S.c0[k], mine, slot);
+                const int run = k == 0 ? run0 : k == 1 ? run1 : run2;
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (mine[u]) A[run + slot[u]] = base + u * QT + tid;
             }
         }
         __syncthreads();
     }
-    // qh_buildhull
+    // qh_buildhull.  One thread keeps the facet list; between two of its turns the workgroup partitions the outside
+    // sets of the visible facets.  Two barriers per insertion: behind the thread's turn, and inside the search of the
+    // farthest points.
     unsigned long long visits = 0;
     int steps = 0;
-    for (int step = 0; step < m + 8; step++) {
-        if (tid == 0) {
+    // the next insertion: qh_nextfurthest, qh_findhorizon, qh_makenew_simplicial
+    auto next_insertion = [&]() {
             const double minvisible = S.thr[1];
             while (S.nextf != 0 && S.total[S.nextf] == 0) S.nextf = S.next[S.nextf];           // qh_nextfurthest
             if (S.nextf == 0)
@@ -537,9 +656,12 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                     S.n_unc = 0;
                 }
             }
-        }
-        __syncthreads();
-        if (S.state != 0) break;
+            };
+    ph.mark(3);
+    if (tid == 0) next_insertion();
+    __syncthreads();
+    ph.mark(4);
+    for (int step = 0; step < m + 8 && S.state == 0; step++) {
         // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
         const double apex_x = x[apex], apex_y = y[apex];
@@ -570,6 +692,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                         px[u] = p[u] >= 0 ? x[p[u]] : apex_x;
                         py[u] = p[u] >= 0 ? y[p[u]] : apex_y;
                     }
+                    int cls[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         int c = 2;
@@ -595,9 +718,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                                 }
                             }
                         }
-                        const int s0 = wave_slot(&S.c0[slot], c == 0), s1 = wave_slot(&S.c1[slot], c == 1);
-                        if (c == 0) dst[lo + s0] = p[u];
-                        if (c == 1) dst[lo + cnt - 1 - s1] = p[u];
+                        cls[u] = c;
                         if (c == 0) {
                             if (fi0 < 0 || d > fd0) { fd0 = d; fi0 = p[u]; ft0 = 0; }
                             else if (d == fd0 && !same_point(x, y, p[u], fi0)) ft0 = 1;
@@ -606,16 +727,30 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                             else if (d == fd1 && !same_point(x, y, p[u], fi1)) ft1 = 1;
                         }
                     }
+                    // the points of the first new facet upwards from the piece's start, those of the second
+                    // downwards from its end
+                    bool m0[4], m1[4];
+                    int s0[4], s1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { m0[u] = cls[u] == 0; m1[u] = cls[u] == 1; }
+                    wave_slots<4>(&S.c0[slot], m0, s0);
+                    wave_slots<4>(&S.c1[slot], m1, s1);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (m0[u]) dst[lo + s0[u]] = p[u];
+                        if (m1[u]) dst[lo + cnt - 1 - s1[u]] = p[u];
+                    }
                 }
             }
         }
+        ph.mark(5);
         double od[2];
         int oi[2], ot[2];
-        block_far(S, x, y, fd0, fi0, fd1, fi1, od, oi, ot);
-        if ((ft0 && fi0 >= 0 && fd0 == od[0]) || (ft1 && fi1 >= 0 && fd1 == od[1])) doubt = true;
-        if (doubt) { S.state = 2; S.reason = 10; }
-        __syncthreads();
-        if (tid == 0 && S.state == 0) {
+        block_far(S, x, y, fd0, fi0, ft0, fd1, fi1, ft1, od, oi, ot, doubt);
+        ph.mark(6);
+        if (tid == 0) {
+            if (doubt) { S.state = 2; S.reason = 10; }
+            if (S.state == 0) {
             if (ot[0] || ot[1]) { S.state = 2; S.reason = 4; }
             const int child[2] = {a0, a1};
             for (int k = 0; k < nvis && S.state == 0; k++) {
@@ -710,9 +845,11 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
                 S.visible[v] = 0;
                 S.free_slot[S.n_free++] = (short)v;
             }
+                    }
+            if (S.state == 0) next_insertion();
         }
         __syncthreads();
-        if (S.state != 0) break;
+        ph.mark(4);
     }
     if (tid == 0) {
         int64_t out = QHULL_DEFER;
@@ -777,6 +914,7 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
         start[s] = out;
         if (start_xy && out >= 0) { start_xy[2 * s] = x[out]; start_xy[2 * s + 1] = y[out]; }
     }
+    ph.mark(7);
 }
 
 }  // namespace
@@ -788,11 +926,24 @@ __global__ __launch_bounds__(QT, 3) void qhull_order_kernel(const double *__rest
 // scratch: 2 * total int32 entries.
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                     const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
-                    int64_t *start, double *start_xy, hipStream_t st)
+                    int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull)
 {
     if (n_slices <= 0) return PCFIT_OK;
-    qhull_order_kernel<<<dim3((unsigned)n_slices), dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, scratch,
-                                                                    scratch + total, start, start_xy);
+    // The form with the fewest facet slots that holds every hull of the batch twice over (a slice that runs out of
+    // slots all the same is handed back): fewer slots, more slices in flight on a CU.
+    static const int forced = [] { const char *e = getenv("PCFIT_QHULL_FORM"); return e ? atoi(e) : 0; }();
+    const int64_t need = max_hull < 0 ? QF_MAX : 2 * max_hull + 16;
+    const int form = forced ? forced : need <= 112 ? 112 : need <= 224 ? 224 : QF_MAX;
+    const dim3 grid((unsigned)n_slices), block(QT);
+#define PCFIT_QHULL_LAUNCH(QF, WG)                                                                                  \
+    qhull_order_kernel<QF, WG><<<grid, block, 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, scratch,          \
+                                                       scratch + total, start, start_xy)
+    if (form == 112) PCFIT_QHULL_LAUNCH(112, 6);
+    else if (form == 113) PCFIT_QHULL_LAUNCH(112, 8);
+    else if (form == 224) PCFIT_QHULL_LAUNCH(224, 5);
+    else if (form == 225) PCFIT_QHULL_LAUNCH(224, 4);
+    else PCFIT_QHULL_LAUNCH(QF_MAX, 3);
+#undef PCFIT_QHULL_LAUNCH
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
@@ -815,7 +966,7 @@ PCFIT_API int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, co
         return PCFIT_ERR_WORKSPACE;
     }
     return qhull_start_dev(ux, uy, offsets, n_unique, n_hull, select, n_slices, total_points, static_cast<int *>(scratch),
-                           start, nullptr, as_stream(stream));
+                           start, nullptr, as_stream(stream), -1);
 }
 
 // tools and tests: how many slices the kernel handed back since the last reset, by cause (1 flat simplex, 2 simplex
@@ -833,3 +984,18 @@ PCFIT_API int pcfit_debug_qhull_reasons(int64_t *out16, int reset)
     }
     return PCFIT_OK;
 }
+
+#ifdef PCFIT_PHASE_CLOCK
+// tools only: clocks accumulated per phase by thread 0 of one workgroup in 16 (8 counters)
+PCFIT_API int pcfit_debug_qhull_phase_clocks(int64_t *out8, int reset)
+{
+    PCFIT_ENTER();
+    PCFIT_HIP(hipDeviceSynchronize());
+    PCFIT_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pcfit::g_qphase), 8 * sizeof(int64_t)));
+    if (reset) {
+        int64_t zero[8] = {0};
+        PCFIT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(pcfit::g_qphase), zero, sizeof(zero)));
+    }
+    return PCFIT_OK;
+}
+#endif

@@ -68,7 +68,8 @@ def allgather_slice_arrays(local, bounds, group=None):
     return out
 
 
-REC = 16        # doubles per window in the exchanged record (13 used)
+REC = 16        # doubles per window in the exchanged record (13 used; a batch of scans adds the window's centre
+                # and the number of its scan at 13 and 14)
 
 
 def pack_window_records(h):
@@ -201,7 +202,10 @@ def analyze_sharded(analyzer, points, group=None, progress_callback=None):
         if resident:
             h = _ffi.scan_hybrid_batch(points, lo, hi, *args, order=analyzer.config.hull_order)
         else:
-            with DeviceScan(points, z_range=(lo[0], hi[-1])) as part:
+            # (with a configured range the reference drops what lies outside it first, analyzer.py:191-196: the last
+            # window's upper edge can lie a rounding above z_max, and a row in between is nobody's)
+            z_range = (max(lo[0], analyzer.z_min), min(hi[-1], analyzer.z_max)) if ranged else (lo[0], hi[-1])
+            with DeviceScan(points, z_range=z_range) as part:
                 if len(part):
                     h = _ffi.scan_hybrid_batch(part, lo, hi, *args, order=analyzer.config.hull_order)
                 else:
@@ -220,6 +224,43 @@ def analyze_sharded(analyzer, points, group=None, progress_callback=None):
     return results
 
 
+def allgather_scan_records(mine, group=None):
+    """The per-window results of whole scans, exchanged between the ranks.  ``mine``: {scan number: (z_centers,
+    h)} of the scans this rank analysed (h as _ffi.scan_hybrid_batch returns it; scans without windows left out).
+    Returns the same for the scans of ALL ranks.  One gather of every rank's window count, then the two
+    fixed-size gathers of allgather_window_records; the record of a window carries its centre and the number of
+    its scan, so the receiver needs nothing else to take the stream apart."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    recs, cands = [], []
+    for k in sorted(mine):
+        z_centers, h = mine[k]
+        rec, cand = pack_window_records(h)
+        rec[:, 13] = z_centers
+        rec[:, 14] = k
+        recs.append(rec)
+        cands.append(cand)
+    rec = np.concatenate(recs, axis=0) if recs else np.zeros((0, REC))
+    cand = np.concatenate(cands, axis=1) if cands else np.zeros((2, 0))
+    dev = _collective_device(group)
+    count = torch.tensor([rec.shape[0]], dtype=torch.int64, device=dev)
+    counts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(counts, count, group=group)
+    bounds = np.concatenate([[0], np.cumsum(counts.cpu().numpy())]).astype(np.int64)
+    all_rec, all_cand = allgather_window_records(rec, cand, bounds, group)
+    # the windows of one scan stand together (its owner sent them in window order): cut where the number changes
+    scan_of = all_rec[:, 14].astype(np.int64)
+    c_off = np.concatenate([[0], np.cumsum(all_rec[:, 2].astype(np.int64))])
+    starts = np.flatnonzero(np.diff(scan_of, prepend=-1)) if scan_of.size else np.zeros(0, np.int64)
+    ends = np.append(starts[1:], scan_of.size)
+    out = {}
+    for a, b in zip(starts, ends):
+        out[int(scan_of[a])] = (all_rec[a:b, 13].copy(),
+                                unpack_window_records(all_rec[a:b], all_cand[:, c_off[a]:c_off[b]]))
+    return out
+
+
 def scans_of_rank(n_scans: int, rank: int, world: int):
     """Whole scans go to the ranks round-robin: rank r analyses scans r, r + world, ..."""
     return list(range(rank, n_scans, world))
@@ -231,7 +272,10 @@ def analyze_scans_sharded(analyzer, scans, group=None, progress_callback=None, g
     the next one (a second host thread making the DeviceScan) overlapped with the analysis of the current one.
     ``scans``: a sequence whose items are (N, 3) arrays or callables returning one (so that a rank only loads
     what it analyses).  Returns the list of per-scan result lists, in the order of ``scans``; entries of other
-    ranks are filled in when ``gather`` (all_gather_object of the result dicts), else left as None.
+    ranks are filled in when ``gather``, else left as None.  What travels is what analyze_sharded sends: one
+    packed record per window (here with the window's centre and the number of its scan) and the candidates, in
+    fixed-size all-gathers (RCCL on the GPUs) - after one gather of every rank's window count; each rank then
+    builds the result dicts of all scans from the records, the same dicts its owner built.
     Without an initialised process group the one caller takes every scan."""
     from concurrent.futures import ThreadPoolExecutor
 
@@ -258,26 +302,37 @@ def analyze_scans_sharded(analyzer, scans, group=None, progress_callback=None, g
         item = scans[k]
         pts = item() if callable(item) else item
         pts = np.ascontiguousarray(pts, dtype=np.float64)
-        if pts.ndim != 2 or pts.shape[1] != 3:
-            raise ValueError("Points must be Nx3 array")
-        return DeviceScan(pts)
+        return analyzer._resident(pts)
 
+    def results_of(z_centers, h):
+        res = [r for r, _, warn in analyzer._results_of(z_centers, h) if warn is None]
+        res.sort(key=lambda r: r["z_center"])
+        return res
+
+    exchange = dist is not None and gather and world > 1
     out = [None] * len(scans)
+    packed = {}
     with ThreadPoolExecutor(1) as pool:
         nxt = pool.submit(resident, mine[0]) if mine else None
         for j, k in enumerate(mine):
             cur = nxt.result()
             nxt = pool.submit(resident, mine[j + 1]) if j + 1 < len(mine) else None
             try:
-                out[k] = analyzer.analyze_with_progress(cur)
+                z_centers = analyzer.calculate_z_centers(cur)
+                h = analyzer._hybrid_windows(cur, z_centers) if len(z_centers) else None
             finally:
-                cur.close()
+                if isinstance(cur, DeviceScan):
+                    cur.close()
+            out[k] = results_of(z_centers, h) if h is not None else []
+            if exchange and h is not None:
+                packed[k] = (z_centers, h)
             if progress_callback:
                 progress_callback(int(100 * (j + 1) / len(mine)))
-    if dist is not None and gather and world > 1:
-        everyone = [None] * world
-        dist.all_gather_object(everyone, {k: out[k] for k in mine}, group=group)
-        for part in everyone:
-            for k, res in part.items():
-                out[k] = res
+    if exchange:
+        for k, (z_centers, h) in allgather_scan_records(packed, group).items():
+            if out[k] is None:
+                out[k] = results_of(z_centers, h)
+        for k in range(len(scans)):
+            if out[k] is None:                       # (a scan without a window: its owner sent nothing)
+                out[k] = []
     return out

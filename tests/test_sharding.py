@@ -52,6 +52,12 @@ def test_window_records_travel_packed_over_gloo(world):
     assert r["ok"] and r["world"] == world
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_scan_batch_records_travel_packed_over_gloo(world):
+    r = run_workers(world, "scan_records")
+    assert r["ok"] and r["world"] == world
+
+
 def test_host_passes_over_the_z_column():
     """numpy's min / max and the closed-window populations (shared edges counted twice, NaN nowhere), computed by
     the library's host threads: host code only, no GPU needed."""
@@ -108,10 +114,12 @@ def test_scans_go_round_robin():
 
 
 @pytest.mark.gpu
-def test_batch_of_scans_two_ranks_one_gpu():
-    # five scans over two ranks (3 + 2), uploads overlapped with the analyses, results exchanged over gloo
-    r = run_workers(2, "scans_gpu")
-    assert r["ok"]
+@pytest.mark.parametrize("world", [2, 3])
+def test_batch_of_scans_ranks_share_one_gpu(world):
+    # five scans over two ranks (3 + 2) or three (2 + 2 + 1), uploads overlapped with the analyses, the packed
+    # window records exchanged over gloo, every rank's copy of every scan's results checked
+    r = run_workers(world, "scans_gpu")
+    assert r["ok"] and r["world"] == world
 
 
 @pytest.mark.gpu

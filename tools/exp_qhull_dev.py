@@ -9,8 +9,14 @@ import time
 import numpy as np
 import torch
 
+import os
+
 sys.path.insert(0, ".")
 from pointcloud_amd import _ffi as F
+
+PHASES = os.environ.get("PHASES") == "1"            # the phase-clock build (make -C pointcloud_amd/csrc phase)
+if PHASES:
+    F.SO_PATH = F.SO_PATH.replace("libpcfit_hip.so", "libpcfit_hip_phase.so")
 
 S, n = (int(a) for a in (sys.argv[1:3] + ["2000", "50000"])[:2])
 shift = (float(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (3.0, -2.0)      # where the cylinder stands
@@ -44,3 +50,15 @@ for rep in range(3):
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
     print(f"{e0.elapsed_time(e1):.3f} ms; per slice: {why[14] / S:.1f} insertions, {why[15] / S / n:.2f} visits per point after the "
           f"first partition; handed back {int(why[:14].sum())} {why[:14].tolist()}; mean hull {float(nh.double().mean()):.1f}")
+if PHASES:
+    out = np.zeros(8, np.int64)
+    L = F.lib()
+    L.pcfit_debug_qhull_phase_clocks.argtypes = [C.c_void_p, C.c_int]
+    L.pcfit_debug_qhull_phase_clocks(F._p(out), 1)
+    F.check(L.pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 8, p(start), st))
+    L.pcfit_debug_qhull_phase_clocks(F._p(out), 0)
+    sampled = (S + 15) // 16                       # one workgroup in 16 reports; wall_clock64 ticks at 100 MHz
+    names = ["extremes", "simplex", "first partition", "placing", "the list's thread", "partition of visible sets",
+             "farthest points", "end"]
+    for k, nm in enumerate(names):
+        print(f"   phase {nm:26s} {out[k] / sampled / 100:8.2f} us/slice  {100 * out[k] / max(out.sum(), 1):5.1f} %")
