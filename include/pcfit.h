@@ -378,11 +378,21 @@ int pcfit_qhull_order_batch(const double *ux, const double *uy, const int64_t *o
  * the slice was not selected, PCFIT_QHULL_START_DEFER where the kernel met anything but the plain course of
  * the construction (a decision inside Qhull's roundoff bands, a tie for the farthest point, a flat initial
  * simplex, more than 479 facets alive at once) - those slices are for pcfit_qhull_order_batch.
- * scratch: total_points * 8 bytes of device memory. */
+ * The points may also be the slices as they are (n_unique NULL: any order, duplicates allowed; start[s] then
+ * names one of the copies of the vertex).
+ * hull_x, hull_y, hull_idx (all three or none): the slices' hulls as pcfit_unique_hull_batch_dev left them in
+ * ux, uy, hull_idx - vertex i of slice s at (hull_x, hull_y)[offsets[s] + hull_idx[offsets[s] + i]], i <
+ * n_hull[s]; they need not index the array in ux, uy.  With them the kernel takes the four coordinate extremes
+ * Qhull starts from among the hull's vertices instead of by a pass over the slice.
+ * max_hull: the largest n_hull of the batch, or -1 (unknown): the kernel runs in the form with the fewest
+ * facet slots that holds twice that many, so that more slices are in flight on a compute unit.
+ * scratch: total_points * 48 bytes of device memory, aligned to 16 (the kernel keeps the points outside of the
+ * growing hull as (x, y) pairs in it, so that every pass over them streams). */
 #define PCFIT_QHULL_START_DEFER (-3)
 int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                                 const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total_points,
-                                void *scratch, size_t scratch_bytes, int64_t *start, void *stream);
+                                void *scratch, size_t scratch_bytes, int64_t *start, const double *hull_x,
+                                const double *hull_y, const int64_t *hull_idx, int64_t max_hull, void *stream);
 
 /* How many slices that kernel handed back since the last reset, by cause (out16[1..13]: flat simplex, simplex
  * orientation, first partition near a threshold, tie for the farthest point, horizon near the threshold, more

@@ -91,7 +91,8 @@ SIGNATURES = {
     "pcfit_unique_hull_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pcfit_ovality_batch": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64]),
     "pcfit_qhull_order_batch": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
-    "pcfit_qhull_start_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp]),
+    "pcfit_qhull_start_batch_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp, _vp, _vp, _vp,
+                                              _i64, _vp]),
     "pcfit_debug_qhull_reasons": (C.c_int, [_vp, C.c_int]),
     "pcfit_rank_check_batch": (C.c_int, [_vp, _vp, _vp, _i64, _f64, _vp]),
     "pcfit_circle3_batch": (C.c_int, [_vp, _i64, _vp, _vp]),

@@ -34,12 +34,18 @@ int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, c
 // qhull_dev.hip: the same replay on the device, one workgroup per slice, of slices that are sorted and distinct
 // (n_unique points each) or as they come (n_unique null); start[s] = QHULL_START_DEFER where the host has to
 // decide (anything but the plain course of the construction); start_xy (nullable): the vertex's coordinates.
-// scratch: 2 * total int32 entries.  max_hull: the largest n_hull of the batch when the host knows it (the kernel
-// then runs in the form with the fewest facet slots that suffices), else -1.
+// scratch: 3 * total (x, y) pairs, 48 bytes a point (the outside sets are kept as points, not as indices: every pass
+// over them streams).  want_index = false: start[s] = 0 wherever there is an answer, which saves the pass that
+// finds the vertex's place in its slice.  max_hull: the largest n_hull of the batch when the host knows it (the kernel
+// then runs in the form with the fewest facet slots that suffices), else -1.  hull_x, hull_y, hull_idx (nullable,
+// all three or none): the slices' strictly convex hulls as unique_hull_dev left them - vertex i of slice s is
+// (hull_x, hull_y)[offsets[s] + hull_idx[offsets[s] + i]] - among whose vertices the kernel then finds the
+// coordinate extremes instead of by a pass over the slice.
 constexpr int64_t QHULL_START_DEFER = -3;
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
-                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
-                    int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull);
+                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, void *scratch,
+                    int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull, const double *hull_x,
+                    const double *hull_y, const int64_t *hull_idx, bool want_index);
 
 // longsort.hip: lexicographic sort of (a, b) pairs inside every slice longer than min_len, and the distinct
 // pairs of the sorted slices (see there)

@@ -563,9 +563,9 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
     PCFIT_TRY(dstart.alloc((size_t)S * 8));
     PCFIT_TRY(dxy.alloc((size_t)S * 16));
     if (!on_host) {
-        PCFIT_TRY(dscratch.alloc((size_t)total * 8));
-        PCFIT_TRY(qhull_start_dev(px, py, doff, d_n_pts, dnh, d_hull_start, S, total, dscratch.as<int>(),
-                                  dstart.as<int64_t>(), dxy.as<double>(), st, max_hull));
+        PCFIT_TRY(dscratch.alloc((size_t)total * 48));
+        PCFIT_TRY(qhull_start_dev(px, py, doff, d_n_pts, dnh, d_hull_start, S, total, dscratch.as<void>(),
+                                  dstart.as<int64_t>(), dxy.as<double>(), st, max_hull, dux, duy, dhi, false));
         PCFIT_TRY(dstart.download(start.data(), (size_t)S * 8, st));
         PCFIT_HIP(hipStreamSynchronize(st));
     } else {

@@ -42,7 +42,6 @@ struct QPhase {
 #endif
 namespace {
 
-constexpr int QT = 256;          // threads of a workgroup
 constexpr int QF_MAX = 480;      // live facets of a slice (slot 0 is the list's tail): the kernel's roomiest form
 constexpr int QP = 5;            // pieces an outside set may lie in
 constexpr int QV = 6;            // visible facets of one insertion
@@ -50,23 +49,42 @@ constexpr int QU = 32;           // points of one insertion that go through the 
 constexpr int64_t QHULL_DEFER = QHULL_START_DEFER;
 constexpr unsigned IDX_MASK = 0x7fffffffu;      // a piece's start; the top bit names the buffer it lies in
 
-template <int QF>
+// The farthest point of an outside set as a thread, a wave or the workgroup has seen it: distance and coordinates
+// (has = 0: no point yet), and whether that distance was met at two different points.
+struct Far {
+    double d, x, y;
+    int has, tie;
+    __device__ __forceinline__ void take(double od, double ox, double oy)
+    {
+        if (!has || od > d) { d = od; x = ox; y = oy; has = 1; tie = 0; }
+        else if (od == d && (ox != x || oy != y)) tie = 1;
+    }
+    __device__ __forceinline__ void join(const Far &o)
+    {
+        if (!o.has) return;
+        if (!has || o.d > d) *this = o;
+        else if (o.d == d && (o.x != x || o.y != y)) tie = 1;
+    }
+};
+template <int QF, int QT>
 struct Shared {
-    static constexpr int FACETS = QF;
+    static constexpr int FACETS = QF, THREADS = QT;
     double n0[QF], n1[QF], off[QF];
-    double far_d[QF];
-    int v0[QF], v1[QF], total[QF], far_idx[QF];
+    double far_d[QF], far_x[QF], far_y[QF];      // the farthest point of the outside set (total > 0)
+    double vx0[QF], vy0[QF], vx1[QF], vy1[QF];   // the facet's two vertices
+    int total[QF];
     int plo[QF][QP], pcnt[QF][QP];
     short nb0[QF], nb1[QF], prev[QF], next[QF], free_slot[QF];
     unsigned char np[QF], top[QF], visible[QF];
     // one insertion
     int c0[QV * QP], c1[QV * QP];
-    double wave_d[2][QT / 64];
-    int wave_i[2][QT / 64], wave_tie[2][QT / 64], wave_flag[QT / 64];
-    int vis[QV], nvis, newf[2], apex, state, reason, n_free, head, nextf;
+    Far wave_far[2][QT / 64];
+    int wave_flag[QT / 64];
+    int vis[QV], nvis, newf[2], state, reason, n_free, head, nextf, gap_lo;
+    double apex_x, apex_y;
     // points below both new facets by less than a roundoff unit: Qhull searches the horizon for them
-    int unc_p[QU], unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
-    double unc_d[QU];
+    int unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
+    double unc_d[QU], unc_x[QU], unc_y[QU];
     unsigned short visit[QF], visit_id;
     short copl[64];
     double red_d[QT / 64];
@@ -75,22 +93,30 @@ struct Shared {
     int ext_at[4][QT / 64];
     double thr[6];               // distround, minvisible, minoutside, distoutside, band, (unused)
     double search[3];            // the simplex search: best determinant so far, the one that ends it, near zero
-    int ext[4];
+    double sx[3], sy[3];         // the simplex's vertices: least x, greatest x, the third; at the end: the answer
+    int found;                   // at the end: the answer's place in the slice
 };
+
+// A value that every lane holds alike (read from LDS, which the compiler cannot know), moved to scalar registers.
+__device__ __forceinline__ double uni(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 template <class SH>
 __device__ inline double plane_dist(const SH &S, int f, double x, double y) { return S.off[f] + x * S.n0[f] + y * S.n1[f]; }
 
 template <class SH>
-__device__ inline void set_plane(SH &S, int f, const double *x, const double *y)
+__device__ inline void set_plane(SH &S, int f)
 {
-    const int a = S.v0[f], b = S.v1[f];
-    const double nx = y[b] - y[a], ny = x[a] - x[b];
+    const double ax = S.vx0[f], ay = S.vy0[f], bx = S.vx1[f], by = S.vy1[f];
+    const double nx = by - ay, ny = ax - bx;
     double norm = sqrt(nx * nx + ny * ny);
     if (!S.top[f]) norm = -norm;
     S.n0[f] = nx / norm;
     S.n1[f] = ny / norm;
-    S.off[f] = -(x[a] * S.n0[f] + y[a] * S.n1[f]);
+    S.off[f] = -(ax * S.n0[f] + ay * S.n1[f]);
 }
 
 // qh_removefacet / qh_appendfacet on the list in LDS (one thread)
@@ -118,7 +144,6 @@ __device__ inline bool lex_before(const double *x, const double *y, int a, int b
 {
     return x[a] < x[b] || (x[a] == x[b] && y[a] < y[b]);
 }
-__device__ inline bool same_point(const double *x, const double *y, int a, int b) { return x[a] == x[b] && y[a] == y[b]; }
 
 // The four coordinate extremes in one pass over the slice: least x, greatest x, least y, greatest y, each the
 // lexicographically first point among equals (what "first in the sorted distinct array" means).  Each is an
@@ -142,6 +167,7 @@ __device__ __forceinline__ void key_fold(Key &e, int lane)
 template <class SH>
 __device__ void block_extremes(SH &S, const double *x, const double *y, int m, int out[4])
 {
+    constexpr int QT = SH::THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Key e[4];
 #pragma unroll
@@ -189,52 +215,44 @@ __device__ void block_extremes(SH &S, const double *x, const double *y, int m, i
     }
 }
 
-// The farthest point of each of two classes, over what every thread has seen: (distance, point) per class in
-// out_d / out_i, and whether the greatest distance was met by more than one point; `flag` comes back as the "or"
-// of every thread's.  One barrier: the partials of the last call were read before the barrier that every caller
-// passes between two calls.
 template <int M>
-__device__ __forceinline__ void far_fold(double &d, int &at, int &tie, const double *x, const double *y, int lane)
+__device__ __forceinline__ void far_fold(Far &f, int lane)
 {
     if constexpr (M >= 1) {
-        const double od = lane_xor<M>(d, lane);
-        const int oi = lane_xor_i32<M>(at, lane), ot = lane_xor_i32<M>(tie, lane);
-        if (oi >= 0) {
-            if (at < 0 || od > d) { d = od; at = oi; tie = ot; }
-            else if (od == d && !same_point(x, y, oi, at)) tie = 1;
-        }
-        far_fold<M / 2>(d, at, tie, x, y, lane);
+        Far o;
+        o.d = lane_xor<M>(f.d, lane);
+        o.x = lane_xor<M>(f.x, lane);
+        o.y = lane_xor<M>(f.y, lane);
+        const int word = lane_xor_i32<M>(f.has | (f.tie << 1), lane);
+        o.has = word & 1;
+        o.tie = word >> 1;
+        f.join(o);
+        far_fold<M / 2>(f, lane);
     }
 }
-// t0, t1: this thread has met its own greatest distance at two different points already.
+// The farthest points of two sets over what every thread has seen, to every thread; `flag` comes back as the "or"
+// of every thread's.  One barrier: the partials of the last call were read before the barrier that every caller
+// passes between two calls.
 template <class SH>
-__device__ void block_far(SH &S, const double *x, const double *y, double d0, int i0, int t0, double d1, int i1,
-                          int t1, double out_d[2], int out_i[2], int out_tie[2], bool &flag)
+__device__ void block_far(SH &S, Far &f0, Far &f1, bool &flag)
 {
+    constexpr int QT = SH::THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double d[2] = {d0, d1};
-    int at[2] = {i0, i1}, tie[2] = {t0, t1};
-    far_fold<32>(d[0], at[0], tie[0], x, y, lane);
-    far_fold<32>(d[1], at[1], tie[1], x, y, lane);
+    far_fold<32>(f0, lane);
+    far_fold<32>(f1, lane);
     const bool wave_flag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
     if (lane == 0) {
-        for (int c = 0; c < 2; c++) { S.wave_d[c][wave] = d[c]; S.wave_i[c][wave] = at[c]; S.wave_tie[c][wave] = tie[c]; }
+        S.wave_far[0][wave] = f0;
+        S.wave_far[1][wave] = f1;
         S.wave_flag[wave] = wave_flag ? 1 : 0;
     }
     __syncthreads();
     flag = false;
-    for (int w = 0; w < QT / 64; w++) flag = flag || S.wave_flag[w] != 0;
-    for (int c = 0; c < 2; c++) {
-        out_d[c] = 0.0;
-        out_i[c] = -1;
-        out_tie[c] = 0;
-        for (int w = 0; w < QT / 64; w++) {
-            const double od = S.wave_d[c][w];
-            const int oi = S.wave_i[c][w], ot = S.wave_tie[c][w];
-            if (oi < 0) continue;
-            if (out_i[c] < 0 || od > out_d[c]) { out_d[c] = od; out_i[c] = oi; out_tie[c] = ot; }
-            else if (od == out_d[c] && !same_point(x, y, oi, out_i[c])) out_tie[c] = 1;
-        }
+    f0.has = f1.has = 0;
+    for (int w = 0; w < QT / 64; w++) {
+        flag = flag || S.wave_flag[w] != 0;
+        f0.join(S.wave_far[0][w]);
+        f1.join(S.wave_far[1][w]);
     }
 }
 
@@ -267,16 +285,21 @@ __device__ __forceinline__ void wave_slots(int *counter, const bool (&mine)[U], 
 // QF: facet slots (the LDS a workgroup takes grows with them, and the workgroups a CU holds shrink: every phase of
 // this kernel waits - for memory, for the one thread that keeps the list - so it is the number of slices in
 // flight that fills the chip); WG: workgroups to a CU the registers are budgeted for.
-template <int QF, int WG>
+// QT: threads of the workgroup - 256 for few long slices, one wave when the slices are many: a slice's construction
+// is a chain of short phases, so what fills the chip is the number of slices in flight.
+template <int QF, int WG, int QT>
 __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__restrict__ ux, const double *__restrict__ uy,
                                                          const int64_t *__restrict__ offsets,
                                                          const int64_t *__restrict__ n_unique,
                                                          const int64_t *__restrict__ n_hull,
-                                                         const int64_t *__restrict__ select, int *__restrict__ buf_a,
-                                                         int *__restrict__ buf_b, int64_t *__restrict__ start,
-                                                         double *__restrict__ start_xy)
+                                                         const int64_t *__restrict__ select, double2 *__restrict__ buf_a,
+                                                         double2 *__restrict__ buf_b, int64_t *__restrict__ start,
+                                                         double *__restrict__ start_xy, int want_index,
+                                                         const double *__restrict__ hull_x,
+                                                         const double *__restrict__ hull_y,
+                                                         const int64_t *__restrict__ hull_idx)
 {
-    __shared__ Shared<QF> S;
+    __shared__ Shared<QF, QT> S;
     const int64_t s = blockIdx.x, off = offsets[s];
     const int tid = threadIdx.x;
     if (select && select[s] != PCFIT_HULL_START_QHULL) {
@@ -294,27 +317,65 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     const int m = (int)m64;
     const double *x = ux + off, *y = uy + off;
-    int *const bufs0 = buf_a + off, *const bufs1 = buf_b + off;
+    // The outside sets are kept as the points themselves, (x, y) pairs in runs ("pieces") of two buffers: an
+    // insertion reads the pieces of the visible facets front to back and writes the points that stay outside to
+    // the same entries of the other buffer - no index lists, no gathers.  The first buffer has a slice's m
+    // entries, the second 2 m (what the upper half is for: see the first partition).
+    double2 *const bufs0 = buf_a + off, *const bufs1 = buf_b + 2 * off;
 
     // (the free list and the visit marks: idle until the simplex is made, several barriers from here)
     for (int k = tid; k < QF; k += QT) {
         S.free_slot[k] = (short)(QF - 1 - k);       // slots QF-1 .. 1 (0 is the tail)
         S.visit[k] = 0;
     }
-    // qh_maxmin, qh_detroundoff, qh_maxsimplex
+    // qh_maxmin, qh_detroundoff, qh_maxsimplex.  The four coordinate extremes - least x, greatest x, least y, greatest
+    // y, each the lexicographically first point among equals - by their coordinates: they are vertices of the hull,
+    // so when the caller has the hull they are found among its few vertices instead of by a pass over the slice.
     QPhase ph;
     ph.init();
-    int ext4[4];
-    block_extremes(S, x, y, m, ext4);
+    double ex[4], ey[4];
+    if (hull_x) {
+        const int h = (int)n_hull[s];
+        const double *hx = hull_x + off, *hy = hull_y + off;
+        const int64_t *hi = hull_idx + off;
+        Key e[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) e[k] = {0.0, 0.0, -1};
+        for (int i = tid; i < h; i += QT) {
+            const int v = (int)hi[i];
+            const double px = hx[v], py = hy[v];
+            key_take(e[0], px, py, v);
+            key_take(e[1], -px, py, v);
+            key_take(e[2], py, px, v);
+            key_take(e[3], -py, px, v);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) key_fold<32>(e[k], tid & 63);
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 4; k++) { S.ext_k1[k][tid >> 6] = e[k].k1; S.ext_k2[k][tid >> 6] = e[k].k2; S.ext_at[k][tid >> 6] = e[k].at; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Key r = {0.0, 0.0, -1};
+            for (int w = 0; w < QT / 64; w++) key_take(r, S.ext_k1[k][w], S.ext_k2[k][w], S.ext_at[k][w]);
+            ex[k] = hx[r.at];
+            ey[k] = hy[r.at];
+        }
+    } else {
+        int ext4[4];
+        block_extremes(S, x, y, m, ext4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { ex[k] = x[ext4[k]]; ey[k] = y[ext4[k]]; }
+    }
     ph.mark(0);
-    const int xlo = ext4[0], xhi = ext4[1], ylo = ext4[2], yhi = ext4[3];
+    auto same_xy = [](double ax, double ay, double bx, double by) { return ax == bx && ay == by; };
     if (tid == 0) {
         S.state = 0;
         S.reason = 0;
-        const int ext[4] = {xlo, xhi, ylo, yhi};
-        const double ax = fmax(fabs(x[xlo]), fabs(x[xhi])), ay = fmax(fabs(y[ylo]), fabs(y[yhi]));
+        const double ax = fmax(fabs(ex[0]), fabs(ex[1])), ay = fmax(fabs(ey[2]), fabs(ey[3]));
         const double maxabs = fmax(ax, ay), sumabs = ax + ay;
-        const double maxwidth = fmax(x[xhi] - x[xlo], y[yhi] - y[ylo]);
+        const double maxwidth = fmax(ex[1] - ex[0], ey[3] - ey[2]);
         const double eps = 2.220446049250313e-16;
         const double distround = eps * (2 * fmin(sqrt(2.0) * maxabs, sumabs) * 1.01 + maxabs);
         S.thr[0] = distround;
@@ -322,29 +383,30 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         S.thr[2] = 4 * distround;                  // minoutside
         S.thr[3] = 8 * distround;                  // distoutside
         S.thr[4] = 64 * distround + 8 * distround; // every threshold lies inside this band about zero
-        int minx = ext[0], maxx = ext[0];
+        int minx = 0, maxx = 0;
         for (int k = 0; k < 4; k++) {
-            if (x[ext[k]] > x[maxx]) maxx = ext[k];
-            if (x[ext[k]] < x[minx]) minx = ext[k];
+            if (ex[k] > ex[maxx]) maxx = k;
+            if (ex[k] < ex[minx]) minx = k;
         }
         int third = -1;
         double bestdet = -1.0;
-        if (x[minx] != x[maxx])
+        if (ex[minx] != ex[maxx])
             for (int k = 0; k < 4; k++) {
-                const int i = ext[k];
-                if (same_point(x, y, i, minx) || same_point(x, y, i, maxx)) continue;
-                const double det = fabs((x[minx] - x[i]) * (y[maxx] - y[i]) - (x[maxx] - x[i]) * (y[minx] - y[i]));
-                if (det > bestdet) { bestdet = det; third = i; }
+                if (same_xy(ex[k], ey[k], ex[minx], ey[minx]) || same_xy(ex[k], ey[k], ex[maxx], ey[maxx])) continue;
+                const double det = fabs((ex[minx] - ex[k]) * (ey[maxx] - ey[k]) - (ex[maxx] - ex[k]) * (ey[minx] - ey[k]));
+                if (det > bestdet) { bestdet = det; third = k; }
             }
-        const double target = (x[maxx] - x[minx]) * maxwidth, nearzero = 10 * (80 * sumabs * eps);
-        S.ext[0] = minx; S.ext[1] = maxx; S.ext[2] = third;
+        const double target = (ex[maxx] - ex[minx]) * maxwidth, nearzero = 10 * (80 * sumabs * eps);
+        // the simplex by the coordinates of its vertices: 0 least x, 1 greatest x, 2 the third
+        S.sx[0] = ex[minx]; S.sy[0] = ey[minx];
+        S.sx[1] = ex[maxx]; S.sy[1] = ey[maxx];
+        S.sx[2] = third >= 0 ? ex[third] : 0.0; S.sy[2] = third >= 0 ? ey[third] : 0.0;
         S.search[0] = bestdet; S.search[1] = 10 * 1e-3 * target; S.search[2] = nearzero;
         S.nvis = 0;
-        if (x[minx] == x[maxx])
+        if (ex[minx] == ex[maxx])
             { S.state = 2; S.reason = 1; }          // all points on one vertical line: no hull
         else if (third < 0 || bestdet < nearzero || bestdet / target < 1e-3)
             S.nvis = 1;                             // a flat simplex: Qhull looks through all other points
-        S.vis[0] = xlo; S.vis[1] = xhi; S.vis[2] = ylo; S.vis[3] = yhi;
     }
     __syncthreads();
     if (S.state == 2) {
@@ -354,18 +416,19 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     if (S.nvis == 1) {
         // qh_maxsimplex's search, in the points' order: it stops at the first point that spans a hundredth of what
         // the extents allow (and is not near zero); if none does, the largest determinant wins, the first of equals
-        const int minx = S.ext[0], maxx = S.ext[1];
         const double mindet = S.search[1], nearzero = S.search[2];
-        const double ax = x[minx], ay = y[minx], bx = x[maxx], by = y[maxx];
+        const double ax = S.sx[0], ay = S.sy[0], bx = S.sx[1], by = S.sy[1];
         int first = -1, at = -1;
         double best = -1.0;
         auto larger = [&](double ob, int oa, double b, int a) {
             return oa >= 0 && (a < 0 || ob > b || (ob == b && lex_before(x, y, oa, a)));
         };
         for (int i = tid; i < m; i += QT) {
-            if (same_point(x, y, i, xlo) || same_point(x, y, i, xhi) || same_point(x, y, i, ylo) || same_point(x, y, i, yhi))
+            const double px = x[i], py = y[i];
+            if (same_xy(px, py, ex[0], ey[0]) || same_xy(px, py, ex[1], ey[1]) || same_xy(px, py, ex[2], ey[2]) ||
+                same_xy(px, py, ex[3], ey[3]))
                 continue;
-            const double det = fabs((ax - x[i]) * (by - y[i]) - (bx - x[i]) * (ay - y[i]));
+            const double det = fabs((ax - px) * (by - py) - (bx - px) * (ay - py));
             if (det > mindet && !(det < nearzero) && (first < 0 || lex_before(x, y, i, first))) first = i;
             if (larger(det, i, best, at)) { best = det; at = i; }
         }
@@ -385,9 +448,10 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 if (of >= 0 && (first < 0 || lex_before(x, y, of, first))) first = of;
                 if (larger(S.red_d[w], S.red_i[w], best, at)) { best = S.red_d[w]; at = S.red_i[w]; }
             }
-            if (first >= 0) S.ext[2] = first;
-            else if (at >= 0 && best > S.search[0]) { S.ext[2] = at; S.search[0] = best; }
-            if (first < 0 && (S.ext[2] < 0 || !(S.search[0] > 0.0))) { S.state = 2; S.reason = 1; }
+            bool have = S.search[0] >= 0.0;         // (a third vertex among the extremes)
+            if (first >= 0) { S.sx[2] = x[first]; S.sy[2] = y[first]; have = true; }
+            else if (at >= 0 && best > S.search[0]) { S.sx[2] = x[at]; S.sy[2] = y[at]; S.search[0] = best; have = true; }
+            if (first < 0 && (!have || !(S.search[0] > 0.0))) { S.state = 2; S.reason = 1; }
         }
         __syncthreads();
         if (S.state == 2) {
@@ -396,45 +460,40 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         }
     }
     if (tid == 0) {
-        {
-            const int minx = S.ext[0], maxx = S.ext[1], third = S.ext[2];
-            // qh_createsimplex, qh_initialhull
-            S.n_free = QF - 1;
-            S.visit_id = 0;
-            S.head = S.nextf = 0;
-            S.prev[0] = -1;
-            S.next[0] = 0;
-            const int vs[3] = {third, maxx, minx};
-            int fs[3];
-            bool top = true;
-            for (int i = 0; i < 3; i++) {
-                const int f = S.free_slot[--S.n_free + 0];
-                fs[i] = f;
-                S.v0[f] = vs[i == 0 ? 1 : 0];
-                S.v1[f] = vs[i == 2 ? 1 : 2];
-                S.top[f] = top;
-                S.visible[f] = 0;
-                S.np[f] = 0;
-                S.total[f] = 0;
-                S.far_idx[f] = -1;
-                list_append(S, f);
-                top = !top;
-            }
-            S.nb0[fs[0]] = (short)fs[1]; S.nb1[fs[0]] = (short)fs[2];
-            S.nb0[fs[1]] = (short)fs[0]; S.nb1[fs[1]] = (short)fs[2];
-            S.nb0[fs[2]] = (short)fs[0]; S.nb1[fs[2]] = (short)fs[1];
-            const double cx = (x[minx] + x[maxx] + x[third]) / 3.0, cy = (y[minx] + y[maxx] + y[third]) / 3.0;
-            set_plane(S, fs[0], x, y);
-            if (plane_dist(S, fs[0], cx, cy) > 0)
-                for (int i = 0; i < 3; i++) S.top[fs[i]] = !S.top[fs[i]];
-            for (int i = 0; i < 3; i++) {
-                set_plane(S, fs[i], x, y);
-                if (!(plane_dist(S, fs[i], cx, cy) < -S.thr[4])) { S.state = 2; S.reason = 2; }
-            }
-            S.vis[0] = fs[0]; S.vis[1] = fs[1]; S.vis[2] = fs[2];
-            S.ext[0] = minx; S.ext[1] = maxx; S.ext[2] = third;
-            S.c0[0] = S.c0[1] = S.c0[2] = 0;
+        // qh_createsimplex, qh_initialhull
+        S.n_free = QF - 1;
+        S.visit_id = 0;
+        S.head = S.nextf = 0;
+        S.prev[0] = -1;
+        S.next[0] = 0;
+        const int vs[3] = {2, 1, 0};                // third, greatest x, least x
+        int fs[3];
+        bool top = true;
+        for (int i = 0; i < 3; i++) {
+            const int f = S.free_slot[--S.n_free + 0];
+            fs[i] = f;
+            S.vx0[f] = S.sx[vs[i == 0 ? 1 : 0]]; S.vy0[f] = S.sy[vs[i == 0 ? 1 : 0]];
+            S.vx1[f] = S.sx[vs[i == 2 ? 1 : 2]]; S.vy1[f] = S.sy[vs[i == 2 ? 1 : 2]];
+            S.top[f] = top;
+            S.visible[f] = 0;
+            S.np[f] = 0;
+            S.total[f] = 0;
+            list_append(S, f);
+            top = !top;
         }
+        S.nb0[fs[0]] = (short)fs[1]; S.nb1[fs[0]] = (short)fs[2];
+        S.nb0[fs[1]] = (short)fs[0]; S.nb1[fs[1]] = (short)fs[2];
+        S.nb0[fs[2]] = (short)fs[0]; S.nb1[fs[2]] = (short)fs[1];
+        const double cx = (S.sx[0] + S.sx[1] + S.sx[2]) / 3.0, cy = (S.sy[0] + S.sy[1] + S.sy[2]) / 3.0;
+        set_plane(S, fs[0]);
+        if (plane_dist(S, fs[0], cx, cy) > 0)
+            for (int i = 0; i < 3; i++) S.top[fs[i]] = !S.top[fs[i]];
+        for (int i = 0; i < 3; i++) {
+            set_plane(S, fs[i]);
+            if (!(plane_dist(S, fs[i], cx, cy) < -S.thr[4])) { S.state = 2; S.reason = 2; }
+        }
+        S.vis[0] = fs[0]; S.vis[1] = fs[1]; S.vis[2] = fs[2];
+        S.c0[0] = S.c0[1] = S.c0[2] = 0;
     }
     __syncthreads();
     if (S.state == 2) {
@@ -442,22 +501,21 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         return;
     }
     ph.mark(1);
-    // qh_partitionall: every point to the first of the three facets it lies outside of (counts, then places)
+    // qh_partitionall in one pass: every point to the first of the three facets it lies outside of, and into that
+    // facet's run at once - the first facet's from the start of the first buffer upwards, the second's from entry
+    // m - 1 downwards, the third's from entry m of the second buffer upwards: no two sets may share entries of
+    // [0, m), whichever buffer they are in, and where the first two will end is not known before the end of the
+    // pass.  Once it is, the third set's first move is directed into the gap between them (gap_lo).  With the
+    // farthest point of each set.
     {
         const int f0 = S.vis[0], f1 = S.vis[1], f2 = S.vis[2];
-        const int e0 = S.ext[0], e1 = S.ext[1], e2 = S.ext[2];
-        const double thr = S.thr[3], minoutside = S.thr[2];
-        double fd[3] = {0, 0, 0};
-        int fi[3] = {-1, -1, -1}, ft[3] = {0, 0, 0};
-        bool doubt = false;
-        const double pl[3][3] = {{S.off[f0], S.n0[f0], S.n1[f0]}, {S.off[f1], S.n0[f1], S.n1[f1]}, {S.off[f2], S.n0[f2], S.n1[f2]}};
-        // every point's class goes to a byte array in the second index buffer (idle until the first insertion),
-        // so that the placing pass below reads one byte a point instead of its coordinates
-        unsigned char *cls = reinterpret_cast<unsigned char *>(bufs1);
-        const double e0x = x[e0], e0y = y[e0], e1x = x[e1], e1y = y[e1], e2x = x[e2], e2y = y[e2];
-        // (the loads of the next turn are in flight while this one is classified; a wave counts its classes in
-        // scalar registers and adds them to the workgroup's once, at the end)
-        int n_of[3] = {0, 0, 0};
+        const double thr = uni(S.thr[3]), minoutside = uni(S.thr[2]);
+        Far far[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) far[k] = {0.0, 0.0, 0.0, 0, 0};
+        const double pl[3][3] = {{uni(S.off[f0]), uni(S.n0[f0]), uni(S.n1[f0])}, {uni(S.off[f1]), uni(S.n0[f1]), uni(S.n1[f1])},
+                                 {uni(S.off[f2]), uni(S.n0[f2]), uni(S.n1[f2])}};
+        // (the loads of the next turn are in flight while this one is classified)
         const int last = m - 1;
         auto fetch = [&](double (&qx)[4], double (&qy)[4], int base) {
 #pragma unroll
@@ -468,14 +526,15 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             }
         };
         auto classify = [&](const double (&px)[4], const double (&py)[4], int base) {
+            int cls[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int i = base + u * QT + tid;
                 int c = 3;
                 double d = 0.0;
-                const bool vertex = (px[u] == e0x && py[u] == e0y) || (px[u] == e1x && py[u] == e1y) ||
-                                    (px[u] == e2x && py[u] == e2y);
-                if (!vertex && i < m) {
+                // (the simplex's own vertices need no test: they lie on two of the facets to within the roundoff
+                // of a distance, a quarter of the lower threshold, and below the third)
+                if (i < m) {
                     double most = -1e300;
                     int most_k = 3;
 #pragma unroll
@@ -489,15 +548,26 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                     // it to the facet it is farthest from if that is outside by the lower threshold
                     if (c == 3 && most >= minoutside) { c = most_k; d = most; }
                 }
-                if (i < m) cls[i] = (unsigned char)c;
+                cls[u] = c;
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    n_of[k] += __popcll(__builtin_amdgcn_ballot_w64(c == k));
-                    if (c == k) {
-                        if (fi[k] < 0 || d > fd[k]) { fd[k] = d; fi[k] = i; ft[k] = 0; }
-                        else if (d == fd[k] && !same_point(x, y, i, fi[k])) ft[k] = 1;
+                for (int k = 0; k < 3; k++)
+                    if (c == k) far[k].take(d, px[u], py[u]);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                bool mine[4];
+                int slot[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) mine[u] = cls[u] == k;
+                wave_slots<4>(&S.c0[k], mine, slot);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (mine[u]) {
+                        const double2 xy = make_double2(px[u], py[u]);
+                        if (k == 0) bufs0[slot[u]] = xy;
+                        else if (k == 1) bufs0[last - slot[u]] = xy;
+                        else bufs1[m + slot[u]] = xy;
                     }
-                }
             }
         };
         {
@@ -510,42 +580,30 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 if (base + QT * 4 < m) classify(bx, by, base + QT * 4);
             }
         }
-        if ((tid & 63) == 0)
-            for (int k = 0; k < 3; k++)
-                if (n_of[k]) atomicAdd(&S.c0[k], n_of[k]);
-        if (doubt) { S.state = 2; S.reason = 3; }
         // the farthest point of each of the three sets
-        double od[2];
-        int oi[2], ot[2];
-        double far_d[3];
-        int far_i[3], far_t[3];
+        Far unused = {0.0, 0.0, 0.0, 0, 0};
         bool none = false;
-        block_far(S, x, y, fd[0], fi[0], ft[0], fd[1], fi[1], ft[1], od, oi, ot, none);
-        far_d[0] = od[0]; far_i[0] = oi[0]; far_t[0] = ot[0] | 0;
-        far_d[1] = od[1]; far_i[1] = oi[1]; far_t[1] = ot[1];
+        block_far(S, far[0], far[1], none);
         __syncthreads();                           // (the partials are read: they may be written again)
-        block_far(S, x, y, fd[2], fi[2], ft[2], 0.0, -1, 0, od, oi, ot, none);
-        far_d[2] = od[0]; far_i[2] = oi[0]; far_t[2] = ot[0];
-        __syncthreads();
+        block_far(S, far[2], unused, none);
         if (tid == 0) {
             const int cnt[3] = {S.c0[0], S.c0[1], S.c0[2]};
             const int fs[3] = {f0, f1, f2};
-            int at = 0;
+            const unsigned at[3] = {0u, (unsigned)(m - cnt[1]), 0x80000000u | (unsigned)m};
+            S.gap_lo = cnt[0];
             for (int c = 0; c < 3; c++) {
-                if (far_t[c]) { S.state = 2; S.reason = 4; }
+                if (far[c].has && far[c].tie) { S.state = 2; S.reason = 4; }
                 S.total[fs[c]] = cnt[c];
-                S.far_idx[fs[c]] = far_i[c];
-                S.far_d[fs[c]] = far_d[c];
-                if (cnt[c] > 0) { S.np[fs[c]] = 1; S.plo[fs[c]][0] = at; S.pcnt[fs[c]][0] = cnt[c]; }
-                S.c1[c] = at;                      // where the set's run starts
-                S.c0[c] = 0;
-                at += cnt[c];
+                S.far_x[fs[c]] = far[c].x;
+                S.far_y[fs[c]] = far[c].y;
+                S.far_d[fs[c]] = far[c].d;
+                if (cnt[c] > 0) { S.np[fs[c]] = 1; S.plo[fs[c]][0] = (int)at[c]; S.pcnt[fs[c]][0] = cnt[c]; }
             }
             // qh_furthestnext: the facet with the farthest outside point goes to the front of the list
             int bestf = 0;
             double bestd = -1e300;
             for (int c = 0; c < 3; c++)
-                if (cnt[c] > 0 && far_d[c] > bestd) { bestd = far_d[c]; bestf = fs[c]; }
+                if (cnt[c] > 0 && far[c].d > bestd) { bestd = far[c].d; bestf = fs[c]; }
             if (bestf && bestf != S.head) {
                 list_remove(S, bestf);
                 S.prev[bestf] = -1;
@@ -560,31 +618,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
             return;
         }
-        ph.mark(2);
-        int *A = bufs0;
-        const int run0 = S.c1[0], run1 = S.c1[1], run2 = S.c1[2];
-        for (int base = 0; base < m; base += QT * 4) {
-            int c[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int i = base + u * QT + tid;
-                c[u] = i < m ? (int)cls[i] : 3;
-            }
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                bool mine[4];
-                int slot[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) mine[u] = c[u] == k;
-                wave_slots<4>(&S.c0[k], mine, slot);
-                const int run = k == 0 ? run0 : k == 1 ? run1 : run2;
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (mine[u]) A[run + slot[u]] = base + u * QT + tid;
-            }
-        }
-        __syncthreads();
     }
+    ph.mark(2);
     // qh_buildhull.  One thread keeps the facet list; between two of its turns the workgroup partitions the outside
     // sets of the visible facets.  Two barriers per insertion: behind the thread's turn, and inside the search of the
     // farthest points.
@@ -597,9 +632,10 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             if (S.nextf == 0)
                 S.state = 1;
             else {
-                const int facet = S.nextf, apex = S.far_idx[facet];
-                const double ax = x[apex], ay = y[apex];
-                S.apex = apex;
+                const int facet = S.nextf;
+                const double ax = S.far_x[facet], ay = S.far_y[facet];
+                S.apex_x = ax;
+                S.apex_y = ay;
                 // qh_findhorizon: visible facets move to the end of the list as they are found
                 list_remove(S, facet);
                 list_append(S, facet);
@@ -634,16 +670,17 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                         const int hskip = S.nb0[g] == v ? 0 : 1;
                         if (n_new == 2 || S.n_free == 0) { S.state = 2; S.reason = n_new == 2 ? 7 : 8; break; }
                         const int nf = S.free_slot[--S.n_free];
-                        S.v0[nf] = apex;
-                        S.v1[nf] = hskip ? S.v0[g] : S.v1[g];
+                        S.vx0[nf] = ax;
+                        S.vy0[nf] = ay;
+                        S.vx1[nf] = hskip ? S.vx0[g] : S.vx1[g];
+                        S.vy1[nf] = hskip ? S.vy0[g] : S.vy1[g];
                         S.top[nf] = S.top[g] ? (hskip & 1) != 0 : (hskip & 1) == 0;
                         S.visible[nf] = 0;
                         S.np[nf] = 0;
                         S.total[nf] = 0;
-                        S.far_idx[nf] = -1;
                         S.nb0[nf] = (short)g;
                         if (hskip) S.nb1[g] = (short)nf; else S.nb0[g] = (short)nf;
-                        set_plane(S, nf, x, y);
+                        set_plane(S, nf);
                         list_append(S, nf);
                         S.newf[n_new++] = nf;
                     }
@@ -657,40 +694,37 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 }
             }
             };
-    ph.mark(3);
     if (tid == 0) next_insertion();
     __syncthreads();
     ph.mark(4);
     for (int step = 0; step < m + 8 && S.state == 0; step++) {
         // qh_partitionvisible: the outside points of the visible facets to the first new facet they lie outside of
-        const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], apex = S.apex;
-        const double apex_x = x[apex], apex_y = y[apex];
-        const double minoutside = S.thr[2], reach = S.thr[3], distround = S.thr[0];
-        const double a0_n0 = S.n0[a0], a0_n1 = S.n1[a0], a0_off = S.off[a0];
-        const double a1_n0 = S.n0[a1], a1_n1 = S.n1[a1], a1_off = S.off[a1];
-        double fd0 = 0.0, fd1 = 0.0;
-        int fi0 = -1, fi1 = -1, ft0 = 0, ft1 = 0;
+        const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], gap_lo = S.gap_lo;
+        const double apex_x = uni(S.apex_x), apex_y = uni(S.apex_y);
+        const double minoutside = uni(S.thr[2]), reach = uni(S.thr[3]), distround = uni(S.thr[0]);
+        const double a0_n0 = uni(S.n0[a0]), a0_n1 = uni(S.n1[a0]), a0_off = uni(S.off[a0]);
+        const double a1_n0 = uni(S.n0[a1]), a1_n1 = uni(S.n1[a1]), a1_off = uni(S.off[a1]);
+        Far far0 = {0.0, 0.0, 0.0, 0, 0}, far1 = far0;
         bool doubt = false;
         for (int k = 0; k < nvis; k++) {
             const int v = S.vis[k], np = S.np[v];
             for (int q = 0; q < np; q++) {
                 const unsigned word = (unsigned)S.plo[v][q];
                 const int lo = (int)(word & IDX_MASK), from = (int)(word >> 31), cnt = S.pcnt[v][q], slot = k * QP + q;
-                const int *src = from ? bufs1 : bufs0;
-                int *dst = from ? bufs0 : bufs1;
-                // four points a thread and turn: the gathers of their coordinates are in flight together
+                // (the one piece in the second buffer's upper half - the third set of the first partition - moves
+                // into the gap the other two left)
+                const int to_lo = lo >= m ? gap_lo : lo;
+                const double2 *src = (from ? bufs1 : bufs0) + lo;
+                double2 *dst = (from ? bufs0 : bufs1) + to_lo;
+                // four points a thread and turn (past the piece's end: the apex, which goes nowhere)
                 for (int base = 0; base < cnt; base += QT * 4) {
-                    int p[4];
                     double px[4], py[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const int i = base + u * QT + tid;
-                        p[u] = i < cnt ? src[lo + i] : -1;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        px[u] = p[u] >= 0 ? x[p[u]] : apex_x;
-                        py[u] = p[u] >= 0 ? y[p[u]] : apex_y;
+                        const double2 xy = src[i < cnt ? i : cnt - 1];
+                        px[u] = i < cnt ? xy.x : apex_x;
+                        py[u] = i < cnt ? xy.y : apex_y;
                     }
                     int cls[4];
 #pragma unroll
@@ -710,7 +744,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                                     // below both by less than a roundoff unit: the horizon search, after the pass
                                     const int at = atomicAdd(&S.n_unc, 1);
                                     if (at < QU) {
-                                        S.unc_p[at] = p[u];
+                                        S.unc_x[at] = px[u];
+                                        S.unc_y[at] = py[u];
                                         S.unc_slot[at] = slot;
                                         S.unc_from[at] = d > d0 ? a1 : a0;
                                         S.unc_d[at] = fmax(d0, d);
@@ -719,13 +754,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                             }
                         }
                         cls[u] = c;
-                        if (c == 0) {
-                            if (fi0 < 0 || d > fd0) { fd0 = d; fi0 = p[u]; ft0 = 0; }
-                            else if (d == fd0 && !same_point(x, y, p[u], fi0)) ft0 = 1;
-                        } else if (c == 1) {
-                            if (fi1 < 0 || d > fd1) { fd1 = d; fi1 = p[u]; ft1 = 0; }
-                            else if (d == fd1 && !same_point(x, y, p[u], fi1)) ft1 = 1;
-                        }
+                        if (c == 0) far0.take(d, px[u], py[u]);
+                        else if (c == 1) far1.take(d, px[u], py[u]);
                     }
                     // the points of the first new facet upwards from the piece's start, those of the second
                     // downwards from its end
@@ -737,27 +767,26 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                     wave_slots<4>(&S.c1[slot], m1, s1);
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        if (m0[u]) dst[lo + s0[u]] = p[u];
-                        if (m1[u]) dst[lo + cnt - 1 - s1[u]] = p[u];
+                        if (m0[u]) dst[s0[u]] = make_double2(px[u], py[u]);
+                        if (m1[u]) dst[cnt - 1 - s1[u]] = make_double2(px[u], py[u]);
                     }
                 }
             }
         }
         ph.mark(5);
-        double od[2];
-        int oi[2], ot[2];
-        block_far(S, x, y, fd0, fi0, ft0, fd1, fi1, ft1, od, oi, ot, doubt);
+        block_far(S, far0, far1, doubt);
         ph.mark(6);
         if (tid == 0) {
             if (doubt) { S.state = 2; S.reason = 10; }
             if (S.state == 0) {
-            if (ot[0] || ot[1]) { S.state = 2; S.reason = 4; }
+            if ((far0.has && far0.tie) || (far1.has && far1.tie)) { S.state = 2; S.reason = 4; }
             const int child[2] = {a0, a1};
             for (int k = 0; k < nvis && S.state == 0; k++) {
                 const int v = S.vis[k], np = S.np[v];
                 for (int q = 0; q < np; q++) {
                     const unsigned word = (unsigned)S.plo[v][q];
-                    const int lo = (int)(word & IDX_MASK), to = (int)(word >> 31) ^ 1, cnt = S.pcnt[v][q], slot = k * QP + q;
+                    const int from_lo = (int)(word & IDX_MASK), lo = from_lo >= m ? gap_lo : from_lo;
+                    const int to = (int)(word >> 31) ^ 1, cnt = S.pcnt[v][q], slot = k * QP + q;
                     const int c0 = S.c0[slot], c1 = S.c1[slot];
                     const int at[2] = {lo, lo + cnt - c1}, n[2] = {c0, c1};
                     for (int c = 0; c < 2; c++) {
@@ -771,10 +800,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                     }
                 }
             }
-            S.far_idx[a0] = oi[0];
-            S.far_idx[a1] = oi[1];
-            S.far_d[a0] = od[0];
-            S.far_d[a1] = od[1];
+            S.far_x[a0] = far0.x; S.far_y[a0] = far0.y; S.far_d[a0] = far0.d;
+            S.far_x[a1] = far1.x; S.far_y[a1] = far1.y; S.far_d[a1] = far1.d;
             // qh_findbesthorizon for the points that lie below both new facets by less than a roundoff unit
             // (whatever mode Qhull's search is in by then, it ends in this walk): over neighbours whose distance
             // is no more than the search distance below the best one found; the point joins the facet found if it
@@ -783,8 +810,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             int moved = 0;
             const double searchdist = S.thr[0] * 2 + S.thr[1];
             for (int k = 0; k < S.n_unc && S.state == 0; k++) {
-                const int p = S.unc_p[k];
-                const double px = x[p], py = y[p];
+                const double px = S.unc_x[k], py = S.unc_y[k];
                 double bestdist = S.unc_d[k], minsearch = bestdist - searchdist;
                 int bestf = S.unc_from[k], facet = bestf, nextfacet = 0, size = 0;
                 const unsigned short id = ++S.visit_id;
@@ -820,19 +846,19 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                     moved = 1;
                     list_remove(S, bestf);
                     list_append(S, bestf);
-                    S.far_idx[bestf] = p;
+                    S.far_x[bestf] = px; S.far_y[bestf] = py;
                     S.far_d[bestf] = bestdist;
                 } else if (S.far_d[bestf] < bestdist) {
-                    S.far_idx[bestf] = p;
+                    S.far_x[bestf] = px; S.far_y[bestf] = py;
                     S.far_d[bestf] = bestdist;
                 }
                 if (S.np[bestf] == QP) { S.state = 2; S.reason = 11; break; }
                 // a one-point piece in the gap the dropped points left in the piece this point came from
                 const int slot = S.unc_slot[k], v = S.vis[slot / QP], q = slot % QP;
                 const unsigned word = (unsigned)S.plo[v][q];
-                const int lo = (int)(word & IDX_MASK), to = (int)(word >> 31) ^ 1;
+                const int from_lo = (int)(word & IDX_MASK), lo = from_lo >= m ? gap_lo : from_lo, to = (int)(word >> 31) ^ 1;
                 const int at = lo + S.c0[slot] + S.gap_used[slot]++;
-                (to ? bufs1 : bufs0)[at] = p;
+                (to ? bufs1 : bufs0)[at] = make_double2(px, py);
                 S.plo[bestf][S.np[bestf]] = (int)((unsigned)at | ((unsigned)to << 31));
                 S.pcnt[bestf][S.np[bestf]] = 1;
                 S.np[bestf]++;
@@ -852,7 +878,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         ph.mark(4);
     }
     if (tid == 0) {
-        int64_t out = QHULL_DEFER;
+        bool answered = false;
         if (S.state == 1) {
             // scipy's walk from the head of the list; facets in one line are one facet in Qhull's result (it merged
             // them), standing in the list where the newest part stands.  (The free list, the visit marks and the
@@ -860,9 +886,9 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             short *walk = S.free_slot;
             unsigned short *place = S.visit;
             unsigned char *joined = S.visible;
-            int m = 0, k = 0;
-            for (int f = S.head; m < QF;) {
-                walk[m++] = (short)f;
+            int nw = 0, k = 0;
+            for (int f = S.head; nw < QF;) {
+                walk[nw++] = (short)f;
                 f = S.top[f] ? S.nb0[f] : S.nb1[f];
                 if (f == S.head) break;
             }
@@ -870,28 +896,28 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             const double radius = 2 * S.thr[0];
             int n_joined = 0;
             auto centrum_dist = [&](int of, int to) {          // a facet's centrum, brought onto its own line, from another's line
-                double cx = (x[S.v0[of]] + x[S.v1[of]]) / 2, cy = (y[S.v0[of]] + y[S.v1[of]]) / 2;
+                double cx = (S.vx0[of] + S.vx1[of]) / 2, cy = (S.vy0[of] + S.vy1[of]) / 2;
                 const double own = plane_dist(S, of, cx, cy);
                 cx -= own * S.n0[of];
                 cy -= own * S.n1[of];
                 return plane_dist(S, to, cx, cy);
             };
-            for (int i = 0; i < m; i++) {
-                const int b = walk[i], a = walk[(i + m - 1) % m];
+            for (int i = 0; i < nw; i++) {
+                const int b = walk[i], a = walk[(i + nw - 1) % nw];
                 joined[i] = fabs(centrum_dist(b, a)) <= radius || fabs(centrum_dist(a, b)) <= radius;
                 n_joined += joined[i];
             }
-            if (m - n_joined < 3) {
-                for (int i = 0; i < m; i++) joined[i] = 0;
+            if (nw - n_joined < 3) {
+                for (int i = 0; i < nw; i++) joined[i] = 0;
                 n_joined = 0;
             }
             int first = 0;
             while (joined[first]) first++;
             int count = 0, run_first = first, run_place = 0, best_first = first, best_place = 0x7fffffff;
-            for (int t = 0, i = first; t <= m; t++, i = (i + 1) % m) {
-                if (t == m || !joined[i]) {
+            for (int t = 0, i = first; t <= nw; t++, i = (i + 1) % nw) {
+                if (t == nw || !joined[i]) {
                     if (t > 0 && run_place < best_place) { best_place = run_place; best_first = run_first; }
-                    if (t == m) break;
+                    if (t == nw) break;
                     count++;
                     run_first = i;
                     run_place = place[walk[i]];
@@ -901,18 +927,35 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             // the hull the other kernel found by an exact predicate has these vertices and, where coordinates were
             // rounded, some at the slightest of turns that Qhull does not keep (the turn of the walk takes them out);
             // fewer there than here would mean that something was missed
-            if (m == k && count <= n_hull[s]) {
+            if (nw == k && count <= n_hull[s]) {
                 const int h = walk[best_first];
-                out = S.top[h] ? S.v0[h] : S.v1[h];
+                S.sx[0] = S.top[h] ? S.vx0[h] : S.vx1[h];
+                S.sy[0] = S.top[h] ? S.vy0[h] : S.vy1[h];
+                answered = true;
             } else
                 S.reason = 12;
         } else if (S.state == 0)
             S.reason = 13;
-        if (out == QHULL_DEFER) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
+        if (!answered) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
         atomicAdd(&g_qhull_reason[14], (unsigned long long)steps);
         atomicAdd(&g_qhull_reason[15], visits);
-        start[s] = out;
-        if (start_xy && out >= 0) { start_xy[2 * s] = x[out]; start_xy[2 * s + 1] = y[out]; }
+        S.found = answered ? 0x7fffffff : -1;
+    }
+    __syncthreads();
+    const bool answered = S.found >= 0;
+    if (answered && want_index) {
+        // which point of the slice that is (the first of its copies): one more pass, for callers that ask
+        const double vx = S.sx[0], vy = S.sy[0];
+        int at = 0x7fffffff;
+        for (int i = tid; i < m; i += QT)
+            if (x[i] == vx && y[i] == vy && i < at) at = i;
+        if (at != 0x7fffffff) atomicMin(&S.found, at);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // (without the pass the answer's coordinates are the result, and start[s] = 0 says that there is one)
+        start[s] = !answered ? QHULL_DEFER : want_index ? (S.found == 0x7fffffff ? QHULL_DEFER : S.found) : 0;
+        if (start_xy && answered) { start_xy[2 * s] = S.sx[0]; start_xy[2 * s + 1] = S.sy[0]; }
     }
     ph.mark(7);
 }
@@ -923,26 +966,35 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
 // QHULL_DEFER where the host has to decide; start_xy (nullable): its coordinates.  The points of a slice may
 // come sorted and distinct (n_unique of them) or as they are (n_unique null: the whole slice, any order,
 // duplicates allowed - the answer is the same point, its index then names one of its copies).
-// scratch: 2 * total int32 entries.
+// scratch: 3 * total (x, y) pairs = 48 bytes a point.  want_index = false: start[s] = 0 wherever there is an answer
+// (its coordinates are in start_xy), which saves the pass that finds the point's place in its slice.
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
-                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, int *scratch,
-                    int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull)
+                    const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, void *scratch,
+                    int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull, const double *hull_x,
+                    const double *hull_y, const int64_t *hull_idx, bool want_index)
 {
     if (n_slices <= 0) return PCFIT_OK;
     // The form with the fewest facet slots that holds every hull of the batch twice over (a slice that runs out of
     // slots all the same is handed back): fewer slots, more slices in flight on a CU.
     static const int forced = [] { const char *e = getenv("PCFIT_QHULL_FORM"); return e ? atoi(e) : 0; }();
     const int64_t need = max_hull < 0 ? QF_MAX : 2 * max_hull + 16;
-    const int form = forced ? forced : need <= 112 ? 112 : need <= 224 ? 224 : QF_MAX;
-    const dim3 grid((unsigned)n_slices), block(QT);
-#define PCFIT_QHULL_LAUNCH(QF, WG)                                                                                  \
-    qhull_order_kernel<QF, WG><<<grid, block, 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, scratch,          \
-                                                       scratch + total, start, start_xy)
-    if (form == 112) PCFIT_QHULL_LAUNCH(112, 6);
-    else if (form == 113) PCFIT_QHULL_LAUNCH(112, 8);
-    else if (form == 224) PCFIT_QHULL_LAUNCH(224, 5);
-    else if (form == 225) PCFIT_QHULL_LAUNCH(224, 4);
-    else PCFIT_QHULL_LAUNCH(QF_MAX, 3);
+    // (the forms of one wave per slice - 161, 225, 481 - measured slower at every batch size tried: they are kept
+    // for PCFIT_QHULL_FORM only)
+    const int form = forced ? forced : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;
+    const dim3 grid((unsigned)n_slices);
+    double2 *const pairs = reinterpret_cast<double2 *>(scratch);
+#define PCFIT_QHULL_LAUNCH(QF, WG, QT)                                                                              \
+    qhull_order_kernel<QF, WG, QT><<<grid, dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, pairs,     \
+                                                              pairs + total, start, start_xy, want_index ? 1 : 0, \
+                                                              hull_x, hull_y, hull_idx)
+    switch (form) {
+    case 160: PCFIT_QHULL_LAUNCH(160, 5, 256); break;
+    case 161: PCFIT_QHULL_LAUNCH(160, 8, 64); break;
+    case 224: PCFIT_QHULL_LAUNCH(224, 5, 256); break;
+    case 225: PCFIT_QHULL_LAUNCH(224, 6, 64); break;
+    case QF_MAX + 1: PCFIT_QHULL_LAUNCH(QF_MAX, 3, 64); break;
+    default: PCFIT_QHULL_LAUNCH(QF_MAX, 3, 256); break;
+    }
 #undef PCFIT_QHULL_LAUNCH
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
@@ -955,18 +1007,22 @@ using namespace pcfit;
 PCFIT_API int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_t *offsets,
                                           const int64_t *n_unique, const int64_t *n_hull, const int64_t *select,
                                           int64_t n_slices, int64_t total_points, void *scratch, size_t scratch_bytes,
-                                          int64_t *start, void *stream)
+                                          int64_t *start, const double *hull_x, const double *hull_y,
+                                          const int64_t *hull_idx, int64_t max_hull, void *stream)
 {
     PCFIT_ENTER();
     PCFIT_REQUIRE(n_slices >= 0 && n_slices < (1ll << 31) && total_points >= 0, "qhull_start: sizes out of range");
+    PCFIT_REQUIRE((hull_x != nullptr) == (hull_y != nullptr) && (hull_x != nullptr) == (hull_idx != nullptr),
+                  "qhull_start: hull_x, hull_y and hull_idx come together or not at all");
     if (n_slices == 0) return PCFIT_OK;
     PCFIT_REQUIRE(ux && uy && offsets && n_hull && start, "qhull_start: null pointer");
-    if (!scratch || scratch_bytes < (size_t)total_points * 8) {
-        set_error("qhull_start: the scratch buffer holds %zu bytes, %zu needed", scratch_bytes, (size_t)total_points * 8);
+    if (!scratch || scratch_bytes < (size_t)total_points * 48 || ((uintptr_t)scratch & 15)) {
+        set_error("qhull_start: the scratch buffer holds %zu bytes, %zu needed (aligned to 16)", scratch_bytes,
+                  (size_t)total_points * 48);
         return PCFIT_ERR_WORKSPACE;
     }
-    return qhull_start_dev(ux, uy, offsets, n_unique, n_hull, select, n_slices, total_points, static_cast<int *>(scratch),
-                           start, nullptr, as_stream(stream), -1);
+    return qhull_start_dev(ux, uy, offsets, n_unique, n_hull, select, n_slices, total_points, scratch, start,
+                           nullptr, as_stream(stream), max_hull < 0 ? -1 : max_hull, hull_x, hull_y, hull_idx, true);
 }
 
 // tools and tests: how many slices the kernel handed back since the last reset, by cause (1 flat simplex, 2 simplex

@@ -204,14 +204,33 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
     dx, dy, doff = t(x), t(y), t(off)
     dnu = t(np.diff(off))
     dnh = t(g["count"].astype(np.int64))
-    scratch = torch.empty(total * 8, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(total * 48, dtype=torch.uint8, device=dev)
     start = torch.full((S,), -7, dtype=torch.int64, device=dev)
     why = np.zeros(16, np.int64)
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(dnh), None, S, total, p(scratch),
-                                                total * 8, p(start), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                total * 48, p(start), None, None, None, -1, stream))
     torch.cuda.synchronize()
     got = start.cpu().numpy()
+    # the same with the slices' hulls at hand (the kernel then takes the coordinate extremes from among their
+    # vertices, and runs in the form that the largest of them asks for), in every form the kernel has
+    hh = F.unique_hull_batch(x, y, off)
+    hx, hy, hi, hn = t(hh["ux"]), t(hh["uy"]), t(hh["hull_idx"]), t(hh["n_hull"])
+    for max_hull in (-1, int(hh["n_hull"].max()), 100, 70):
+        again = torch.full((S,), -7, dtype=torch.int64, device=dev)
+        F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(hn), None, S, total, p(scratch),
+                                                    total * 48, p(again), p(hx), p(hy), p(hi), max_hull, stream))
+        torch.cuda.synchronize()
+        again = again.cpu().numpy()
+        both = (again != -3) & (got != -3)
+        assert both.sum() > 600 and np.array_equal(again[both], got[both]), (max_hull, np.flatnonzero(again != got)[:5])
+        if max_hull < 0:                          # the same form: the same slices handed back
+            assert np.array_equal(again, got)
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(dnh), None, S, total, p(scratch),
+                                                total * 48, p(start), None, None, None, -1, stream))
+    torch.cuda.synchronize()
     deferred = got == -3
     assert np.array_equal(got[~deferred], g["first"][~deferred])
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
@@ -255,9 +274,10 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
                 continue
             m = len(uniq)
             st1 = torch.full((1,), -7, dtype=torch.int64, device=dev)
-            sc = torch.empty(m * 8, dtype=torch.uint8, device=dev)
+            sc = torch.empty(m * 48, dtype=torch.uint8, device=dev)
             keep = [t(uniq[:, 0]), t(uniq[:, 1]), t(np.array([0, m])), t(np.array([m])), t(np.array([len(q)]))]
-            F.check(F.lib().pcfit_qhull_start_batch_dev(*[p(a) for a in keep], None, 1, m, p(sc), m * 8, p(st1), None))
+            F.check(F.lib().pcfit_qhull_start_batch_dev(*[p(a) for a in keep], None, 1, m, p(sc), m * 48, p(st1), None,
+                                                        None, None, -1, None))
             torch.cuda.synchronize()
             F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
             assert int(st1.item()) == int(q[0]), (name, i, int(st1.item()), why.tolist())

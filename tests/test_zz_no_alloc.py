@@ -49,12 +49,24 @@ def _run_both(S, n, trials, seed):
                                      p(a["score"]), p(a["best"]), p(a["mask"]), p(a["status"]), p(ws), ws.numel(),
                                      stream))
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated()
-    F.check(L.pcfit_ransac_batch_static_dev(p(dx), p(dy), p(doff), S, 0.5, trials, 0.1, None, p(dtab), p(dof),
-                                            p(b["model"]), p(b["score"]), p(b["best"]), p(b["mask"]), p(b["status"]),
-                                            stream))
-    torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+
+    def static_call(o):
+        F.check(L.pcfit_ransac_batch_static_dev(p(dx), p(dy), p(doff), S, 0.5, trials, 0.1, None, p(dtab), p(dof),
+                                                p(o["model"]), p(o["score"]), p(o["best"]), p(o["mask"]), p(o["status"]),
+                                                stream))
+        torch.cuda.synchronize()
+
+    # "allocates nothing" is read off the device itself: the free bytes hipMemGetInfo reports (torch's own counter
+    # would not see a hipMalloc inside the library) are the same before and after a call - the second one, so
+    # that the address of the library's array has been looked up already; its outputs were allocated before
+    warm = outputs()
+    static_call(warm)
+    free_before = torch.cuda.mem_get_info()[0]
+    static_call(b)
+    assert torch.cuda.mem_get_info()[0] == free_before
+    for k in b:
+        assert torch.equal(warm[k], b[k]) or (b[k].dtype == torch.float64 and
+                                              torch.equal(warm[k].view(torch.int64), b[k].view(torch.int64))), k
     for k in a:
         ha, hb = a[k].cpu().numpy(), b[k].cpu().numpy()
         if ha.dtype == np.float64:

@@ -35,7 +35,11 @@ p = lambda a: C.c_void_p(a.data_ptr())
 # hull sizes from the library (sorted route, once)
 h = F.unique_hull_batch(x.cpu().numpy(), y.cpu().numpy(), off.cpu().numpy())
 nh = torch.from_numpy(h["n_hull"]).to(dev)
-scratch = torch.empty(S * n * 8, dtype=torch.uint8, device=dev)
+# the hulls themselves (HULL=1): the kernel takes the coordinate extremes from them and picks its form by the largest
+HULL = os.environ.get("HULL", "1") == "1"
+hx, hy, hi = (torch.from_numpy(h[k]).to(dev) for k in ("ux", "uy", "hull_idx"))
+hull_args = (p(hx), p(hy), p(hi), int(h["n_hull"].max())) if HULL else (None, None, None, -1)
+scratch = torch.empty(S * n * 48, dtype=torch.uint8, device=dev)
 start = torch.empty(S, dtype=torch.int64, device=dev)
 why = np.zeros(16, np.int64)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -43,8 +47,8 @@ for rep in range(3):
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    F.check(F.lib().pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 8,
-                                                p(start), st))
+    F.check(F.lib().pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 48,
+                                                p(start), *hull_args, st))
     e1.record()
     torch.cuda.synchronize()
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
@@ -55,7 +59,7 @@ if PHASES:
     L = F.lib()
     L.pcfit_debug_qhull_phase_clocks.argtypes = [C.c_void_p, C.c_int]
     L.pcfit_debug_qhull_phase_clocks(F._p(out), 1)
-    F.check(L.pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 8, p(start), st))
+    F.check(L.pcfit_qhull_start_batch_dev(p(x), p(y), p(off), None, p(nh), None, S, S * n, p(scratch), S * n * 48, p(start), *hull_args, st))
     L.pcfit_debug_qhull_phase_clocks(F._p(out), 0)
     sampled = (S + 15) // 16                       # one workgroup in 16 reports; wall_clock64 ticks at 100 MHz
     names = ["extremes", "simplex", "first partition", "placing", "the list's thread", "partition of visible sets",
