@@ -81,6 +81,7 @@ struct Shared {
     Far wave_far[2][QT / 64];
     int wave_flag[QT / 64];
     int vis[QV], nvis, newf[2], state, reason, n_free, head, nextf, gap_lo;
+    int pt_first[QV * QP + 1], pt_word[QV * QP], pt_slot[QV * QP], n_pt;     // the pieces of one insertion, end to end
     double apex_x, apex_y;
     // points below both new facets by less than a roundoff unit: Qhull searches the horizon for them
     int unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
@@ -215,20 +216,28 @@ __device__ void block_extremes(SH &S, const double *x, const double *y, int m, i
     }
 }
 
-template <int M>
-__device__ __forceinline__ void far_fold(Far &f, int lane)
+// The farthest point of a wave's 64: the greatest distance by a fold of the distances alone, then the lanes that
+// hold it are asked for their point (one of them, and whether another one differs from it).  Every lane gets it.
+__device__ __forceinline__ double lane_value(double v, int lane)
 {
-    if constexpr (M >= 1) {
-        Far o;
-        o.d = lane_xor<M>(f.d, lane);
-        o.x = lane_xor<M>(f.x, lane);
-        o.y = lane_xor<M>(f.y, lane);
-        const int word = lane_xor_i32<M>(f.has | (f.tie << 1), lane);
-        o.has = word & 1;
-        o.tie = word >> 1;
-        f.join(o);
-        far_fold<M / 2>(f, lane);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ void far_fold(Far &f)
+{
+    const double top = wave_max(f.has ? f.d : -1.0);            // (distances of outside points are positive)
+    const unsigned long long best = __builtin_amdgcn_ballot_w64(f.has && f.d == top);
+    if (best == 0ull) {
+        f.has = 0;
+        return;
     }
+    const int lane = (int)__builtin_ctzll(best);
+    const double bx = lane_value(f.x, lane), by = lane_value(f.y, lane);
+    const bool differs = f.has && f.d == top && (f.tie || f.x != bx || f.y != by);
+    f.d = top;
+    f.x = bx;
+    f.y = by;
+    f.has = 1;
+    f.tie = __builtin_amdgcn_ballot_w64(differs) != 0ull;
 }
 // The farthest points of two sets over what every thread has seen, to every thread; `flag` comes back as the "or"
 // of every thread's.  One barrier: the partials of the last call were read before the barrier that every caller
@@ -238,8 +247,8 @@ __device__ void block_far(SH &S, Far &f0, Far &f1, bool &flag)
 {
     constexpr int QT = SH::THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    far_fold<32>(f0, lane);
-    far_fold<32>(f1, lane);
+    far_fold(f0);
+    far_fold(f1);
     const bool wave_flag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
     if (lane == 0) {
         S.wave_far[0][wave] = f0;
@@ -302,17 +311,20 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     __shared__ Shared<QF, QT> S;
     const int64_t s = blockIdx.x, off = offsets[s];
     const int tid = threadIdx.x;
+    // The thread that keeps the facet list: the first of one of the workgroup's waves, another one from slice to
+    // slice, so that the list threads of the workgroups that share a compute unit do not all sit on one SIMD.
+    const int lt = 64 * (int)(blockIdx.x % (QT / 64));
     if (select && select[s] != PCFIT_HULL_START_QHULL) {
-        if (tid == 0) start[s] = -1;
+        if (tid == lt) start[s] = -1;
         return;
     }
     const int64_t m64 = n_unique ? n_unique[s] : offsets[s + 1] - off;
     if (m64 < 3 || n_hull[s] < 3) {
-        if (tid == 0) start[s] = -1;
+        if (tid == lt) start[s] = -1;
         return;
     }
     if (m64 >= (1ll << 30) || n_hull[s] > QF - 2) {                // more facets at the end than there are slots
-        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[8], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[8], 1ull); }
         return;
     }
     const int m = (int)m64;
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     ph.mark(0);
     auto same_xy = [](double ax, double ay, double bx, double by) { return ax == bx && ay == by; };
-    if (tid == 0) {
+    if (tid == lt) {
         S.state = 0;
         S.reason = 0;
         const double ax = fmax(fabs(ex[0]), fabs(ex[1])), ay = fmax(fabs(ey[2]), fabs(ey[3]));
@@ -410,7 +422,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     __syncthreads();
     if (S.state == 2) {
-        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
         return;
     }
     if (S.nvis == 1) {
@@ -442,8 +454,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         __syncthreads();
         if ((tid & 63) == 0) { S.red_d[tid >> 6] = best; S.red_i[tid >> 6] = at; S.c0[tid >> 6] = first; }
         __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < QT / 64; w++) {
+        if (tid == lt) {
+            for (int w = 0; w < QT / 64; w++) {         // (its own wave's among them: taken twice, no harm)
                 const int of = S.c0[w];
                 if (of >= 0 && (first < 0 || lex_before(x, y, of, first))) first = of;
                 if (larger(S.red_d[w], S.red_i[w], best, at)) { best = S.red_d[w]; at = S.red_i[w]; }
@@ -455,11 +467,11 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         }
         __syncthreads();
         if (S.state == 2) {
-            if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
             return;
         }
     }
-    if (tid == 0) {
+    if (tid == lt) {
         // qh_createsimplex, qh_initialhull
         S.n_free = QF - 1;
         S.visit_id = 0;
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     __syncthreads();
     if (S.state == 2) {
-        if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
         return;
     }
     ph.mark(1);
@@ -586,7 +598,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         block_far(S, far[0], far[1], none);
         __syncthreads();                           // (the partials are read: they may be written again)
         block_far(S, far[2], unused, none);
-        if (tid == 0) {
+        if (tid == lt) {
             const int cnt[3] = {S.c0[0], S.c0[1], S.c0[2]};
             const int fs[3] = {f0, f1, f2};
             const unsigned at[3] = {0u, (unsigned)(m - cnt[1]), 0x80000000u | (unsigned)m};
@@ -615,7 +627,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         }
         __syncthreads();
         if (S.state == 2) {
-            if (tid == 0) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
             return;
         }
     }
@@ -689,12 +701,24 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 if (S.state == 0) {
                     S.nb1[S.newf[0]] = (short)S.newf[1];
                     S.nb1[S.newf[1]] = (short)S.newf[0];
-                    for (int k = 0; k < QV * QP; k++) S.c0[k] = S.c1[k] = S.gap_used[k] = 0;
+                    // the pieces of the visible facets, end to end: the workgroup goes through them as one run
+                    int n_pt = 0, run = 0;
+                    for (int k = 0; k < nvis; k++)
+                        for (int q = 0; q < S.np[S.vis[k]]; q++) {
+                            const int slot = k * QP + q;
+                            S.c0[slot] = S.c1[slot] = S.gap_used[slot] = 0;
+                            S.pt_first[n_pt] = run;
+                            S.pt_word[n_pt] = S.plo[S.vis[k]][q];
+                            S.pt_slot[n_pt++] = slot;
+                            run += S.pcnt[S.vis[k]][q];
+                        }
+                    S.pt_first[n_pt] = run;
+                    S.n_pt = n_pt;
                     S.n_unc = 0;
                 }
             }
             };
-    if (tid == 0) next_insertion();
+    if (tid == lt) next_insertion();
     __syncthreads();
     ph.mark(4);
     for (int step = 0; step < m + 8 && S.state == 0; step++) {
@@ -706,77 +730,85 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         const double a1_n0 = uni(S.n0[a1]), a1_n1 = uni(S.n1[a1]), a1_off = uni(S.off[a1]);
         Far far0 = {0.0, 0.0, 0.0, 0, 0}, far1 = far0;
         bool doubt = false;
-        for (int k = 0; k < nvis; k++) {
-            const int v = S.vis[k], np = S.np[v];
-            for (int q = 0; q < np; q++) {
-                const unsigned word = (unsigned)S.plo[v][q];
-                const int lo = (int)(word & IDX_MASK), from = (int)(word >> 31), cnt = S.pcnt[v][q], slot = k * QP + q;
+        // The pieces of the visible facets as one run of n_run points, four points a thread and turn (past the end:
+        // the apex, which goes nowhere), so that the loads of a whole insertion - some hundred points in a handful
+        // of pieces, as a rule - are in flight together.
+        const int n_pt = S.n_pt, n_run = S.pt_first[n_pt];
+        for (int base = 0; base < n_run; base += QT * 4) {
+            double px[4], py[4];
+            int piece[4], to_at[4], to_end[4];          // the point's piece, where that piece goes: first and last entry
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = base + u * QT + tid, jj = j < n_run ? j : n_run - 1;
+                int pi = 0;
+                while (jj >= S.pt_first[pi + 1]) pi++;
+                const unsigned word = (unsigned)S.pt_word[pi];
+                const int first = S.pt_first[pi], cnt = S.pt_first[pi + 1] - first;
+                const int lo = (int)(word & IDX_MASK), from = (int)(word >> 31);
                 // (the one piece in the second buffer's upper half - the third set of the first partition - moves
-                // into the gap the other two left)
+                // into the gap the other two left; the top bit of to_at: the buffer it goes to is the first one)
                 const int to_lo = lo >= m ? gap_lo : lo;
-                const double2 *src = (from ? bufs1 : bufs0) + lo;
-                double2 *dst = (from ? bufs0 : bufs1) + to_lo;
-                // four points a thread and turn (past the piece's end: the apex, which goes nowhere)
-                for (int base = 0; base < cnt; base += QT * 4) {
-                    double px[4], py[4];
+                const double2 xy = (from ? bufs1 : bufs0)[lo + (jj - first)];
+                px[u] = j < n_run ? xy.x : apex_x;
+                py[u] = j < n_run ? xy.y : apex_y;
+                piece[u] = pi;
+                to_at[u] = to_lo | (from << 31);
+                to_end[u] = to_lo + cnt - 1;
+            }
+            int cls[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const int i = base + u * QT + tid;
-                        const double2 xy = src[i < cnt ? i : cnt - 1];
-                        px[u] = i < cnt ? xy.x : apex_x;
-                        py[u] = i < cnt ? xy.y : apex_y;
-                    }
-                    int cls[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        int c = 2;
-                        double d = 0.0;
-                        if (px[u] != apex_x || py[u] != apex_y) {
-                            d = a0_off + px[u] * a0_n0 + py[u] * a0_n1;
-                            if (d >= minoutside) {
-                                c = 0;
-                                if (d < reach) doubt = true;        // (Qhull's other search mode may prefer the second facet)
-                            } else {
-                                const double d0 = d;
-                                d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
-                                if (d >= minoutside) c = 1;
-                                else if (fmax(d0, d) >= -distround) {
-                                    // below both by less than a roundoff unit: the horizon search, after the pass
-                                    const int at = atomicAdd(&S.n_unc, 1);
-                                    if (at < QU) {
-                                        S.unc_x[at] = px[u];
-                                        S.unc_y[at] = py[u];
-                                        S.unc_slot[at] = slot;
-                                        S.unc_from[at] = d > d0 ? a1 : a0;
-                                        S.unc_d[at] = fmax(d0, d);
-                                    }
-                                }
+            for (int u = 0; u < 4; u++) {
+                int c = 2;
+                double d = 0.0;
+                if (px[u] != apex_x || py[u] != apex_y) {
+                    d = a0_off + px[u] * a0_n0 + py[u] * a0_n1;
+                    if (d >= minoutside) {
+                        c = 0;
+                        if (d < reach) doubt = true;        // (Qhull's other search mode may prefer the second facet)
+                    } else {
+                        const double d0 = d;
+                        d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
+                        if (d >= minoutside) c = 1;
+                        else if (fmax(d0, d) >= -distround) {
+                            // below both by less than a roundoff unit: the horizon search, after the pass
+                            const int at = atomicAdd(&S.n_unc, 1);
+                            if (at < QU) {
+                                S.unc_x[at] = px[u];
+                                S.unc_y[at] = py[u];
+                                S.unc_slot[at] = S.pt_slot[piece[u]];
+                                S.unc_from[at] = d > d0 ? a1 : a0;
+                                S.unc_d[at] = fmax(d0, d);
                             }
                         }
-                        cls[u] = c;
-                        if (c == 0) far0.take(d, px[u], py[u]);
-                        else if (c == 1) far1.take(d, px[u], py[u]);
                     }
-                    // the points of the first new facet upwards from the piece's start, those of the second
-                    // downwards from its end
-                    bool m0[4], m1[4];
-                    int s0[4], s1[4];
+                }
+                cls[u] = c;
+                if (c == 0) far0.take(d, px[u], py[u]);
+                else if (c == 1) far1.take(d, px[u], py[u]);
+            }
+            // the points of the first new facet upwards from their piece's start, those of the second downwards from
+            // its end; a wave's points of one turn lie in consecutive pieces (one, as a rule)
+            const int p_first = __builtin_amdgcn_readfirstlane(piece[0]), p_last = __builtin_amdgcn_readlane(piece[3], 63);
+            for (int p = p_first; p <= p_last; p++) {
+                const int slot = S.pt_slot[p];
+                bool m0[4], m1[4];
+                int s0[4], s1[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { m0[u] = cls[u] == 0; m1[u] = cls[u] == 1; }
-                    wave_slots<4>(&S.c0[slot], m0, s0);
-                    wave_slots<4>(&S.c1[slot], m1, s1);
+                for (int u = 0; u < 4; u++) { m0[u] = cls[u] == 0 && piece[u] == p; m1[u] = cls[u] == 1 && piece[u] == p; }
+                wave_slots<4>(&S.c0[slot], m0, s0);
+                wave_slots<4>(&S.c1[slot], m1, s1);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (m0[u]) dst[s0[u]] = make_double2(px[u], py[u]);
-                        if (m1[u]) dst[cnt - 1 - s1[u]] = make_double2(px[u], py[u]);
-                    }
+                for (int u = 0; u < 4; u++) {
+                    double2 *dst = to_at[u] < 0 ? bufs0 : bufs1;
+                    if (m0[u]) dst[(to_at[u] & (int)IDX_MASK) + s0[u]] = make_double2(px[u], py[u]);
+                    if (m1[u]) dst[to_end[u] - s1[u]] = make_double2(px[u], py[u]);
                 }
             }
         }
         ph.mark(5);
         block_far(S, far0, far1, doubt);
         ph.mark(6);
-        if (tid == 0) {
+        if (tid == lt) {
             if (doubt) { S.state = 2; S.reason = 10; }
             if (S.state == 0) {
             if ((far0.has && far0.tie) || (far1.has && far1.tie)) { S.state = 2; S.reason = 4; }
@@ -877,7 +909,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         __syncthreads();
         ph.mark(4);
     }
-    if (tid == 0) {
+    if (tid == lt) {
         bool answered = false;
         if (S.state == 1) {
             // scipy's walk from the head of the list; facets in one line are one facet in Qhull's result (it merged
@@ -952,7 +984,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         if (at != 0x7fffffff) atomicMin(&S.found, at);
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == lt) {
         // (without the pass the answer's coordinates are the result, and start[s] = 0 says that there is one)
         start[s] = !answered ? QHULL_DEFER : want_index ? (S.found == 0x7fffffff ? QHULL_DEFER : S.found) : 0;
         if (start_xy && answered) { start_xy[2 * s] = S.sx[0]; start_xy[2 * s + 1] = S.sy[0]; }
