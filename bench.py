@@ -57,6 +57,17 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def kernel_sources_sha1():
+    """Digest of the sources the fused fit + residual kernel is built from: counters recorded under profiles/ speak
+    for the kernel only as long as this has not changed."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("fit.hip", "fit_math.h", "pcfit_internal.h", "angle_math.h", "segments.h"):
+        with open(os.path.join(ROOT, "pointcloud_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _cpu_step_np(x, y, off, s, bins, lo, hi):
     """The step for slice s as the numpy restatement of the reference evaluates it (Kasa -> LM -> residuals)."""
     from oracle import ref_np as R
@@ -160,7 +171,10 @@ def extra_configs(L, dev, stream):
         "ms": ms, "points_per_s": S * n / (ms * 1e-3), "point_hypotheses_per_s": evals / (ms * 1e-3),
         "tflops_at_7_flop": evals * 7 / (ms * 1e-3) / 1e12,
         "valu_fp64_frac": evals * 7 / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS,
-        "min_score": int(score.min().item()), "all_ok": bool((st == 0).all().item())}
+        "min_score": int(score.min().item()), "all_ok": bool((st == 0).all().item()),
+        "roofline": {"kernel": "ransac_score_kernel (1024 hypotheses a slice, 7 flop a point and hypothesis)",
+                     "bound": "valu_fp64", "achieved": evals * 7 / (ms * 1e-3) / 1e12, "peak": PEAK_FP64_VALU_TFLOPS,
+                     "unit": "TFLOP/s", "frac": evals * 7 / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}}
     del x, y, off, tab, tof, model, score, best, st, mask, ws
     torch.cuda.empty_cache()
 
@@ -203,7 +217,13 @@ def extra_configs(L, dev, stream):
         "ms": ms, "ms_level1_and_counts": ms_count, "ms_level2_scatter": ms_scatter,
         "points_per_s": n / (ms * 1e-3), "status": int(status.item()), "members": int(off[-1].item()),
         "gbs_at_64_bytes_per_point_single_pass": 64.0 * n / (ms * 1e-3) / 1e9,
-        "hbm_frac_at_64_bytes_per_point": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        "hbm_frac_at_64_bytes_per_point": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+        # against what a single pass would move (24 read, 16 written... counted as 64 with the count pass); the two
+        # levels move 104.6 bytes a point by the counters (profiles/r03_bin100m_pmc_hbm.txt)
+        "roofline": {"kernel": "bin_count + bin_scatter_staged level 1 + level 2 (five kernels and their scans)",
+                     "bound": "hbm", "achieved": 64.0 * n / (ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": 64.0 * n / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": 64.0 * n,
+                     "traffic": 104.59 * n, "traffic_source": "profiles/r03_bin100m_pmc_hbm.txt"}}
     # the analyzer's own path on that scan (CylinderAnalyzer.analyze_with_progress underneath: binning, interior
     # filter, unique + hull, seeded RANSAC on the hull, Kasa + LM on the inliers, ovality), the scan resident in
     # HBM (pcfit_scan_upload once, as the reference keeps a loaded scan in memory); per-window results and the
@@ -472,6 +492,9 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             traffic = json.load(open(tpath))
+        # counters of an earlier profiler run (tools/profile_bench.sh + tools/summarize_profile.py): only if the
+        # kernel's sources are still the ones they were measured on
+        fresh = bool(traffic) and traffic.get("kernel_sources_sha1") == kernel_sources_sha1()
         tf = flop_launch / (k_ms * 1e-3) / 1e12
         out = {
             "metric": "points fitted/sec (circle fit+residuals)",
@@ -500,7 +523,9 @@ def main():
                 "bound": "hbm",
                 "achieved": alg_bytes / (k_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": alg_bytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                "traffic": traffic.get("fit_residual_kernel_bytes"),
+                "traffic": traffic.get("fit_residual_kernel_bytes") if fresh else None,
+                "traffic_source": (traffic.get("source") if fresh else
+                                   "none: profiles/traffic.json was measured on other kernel sources" if traffic else None),
                 "avg_launch_ms": k_ms,
                 "algorithmic_bytes": alg_bytes,
             },
@@ -511,6 +536,13 @@ def main():
                 "flop_per_point": flop_launch / (S * n),
                 "mean_sweeps": float(sweeps.mean()),
                 "avg_launch_ms": k_ms,
+                # The peak is 256 CUs x 64 lanes x 2 flop at 2.4 GHz; under this kernel the counters show a clock near
+                # 2.0 GHz (SQ_BUSY_CYCLES / 32 engines / launch time), so a kernel that filled every issue slot with
+                # an FMA would read 0.82 here.  Below: the share of the SIMDs' cycles in which this kernel issued a
+                # vector instruction and the instructions it issued per point, from the last profiler run on these
+                # sources (null when the sources have changed since).
+                "valu_issue_frac_last_pmc": traffic.get("fit_residual_kernel_valu_issue_frac") if fresh else None,
+                "valu_insts_per_point_last_pmc": traffic.get("fit_residual_kernel_valu_insts_per_point") if fresh else None,
             },
             "kernels": side,
         }

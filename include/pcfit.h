@@ -398,7 +398,9 @@ int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, const int64_
  * orientation, first partition near a threshold, tie for the farthest point, horizon near the threshold, more
  * than 8 visible facets, new facets, facet slots, nearly collinear facets, partition near a threshold, pieces
  * of an outside set, vertex count, steps; out16[14], out16[15]: insertions made and points visited after the
- * first partition).  For tools and tests; synchronises the device. */
+ * first partition).  For tools and tests; synchronises the device.  The kernel counts from the first call of
+ * this function in the process on (call it once with reset = 1 before the launches to be counted): launches of a
+ * process that never calls it write nothing but their results. */
 int pcfit_debug_qhull_reasons(int64_t *out16, int reset);
 
 /* _has_enough_2d_variation (circle_fitting.py:14-19) per slice: ok[s] = 1 when

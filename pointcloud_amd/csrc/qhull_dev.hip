@@ -12,10 +12,20 @@
 // the exact hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "pcfit_internal.h"
 
 namespace pcfit {
-__device__ unsigned long long g_qhull_reason[16];      // slices handed back, by cause (tools and tests)
+// Slices handed back, by cause, for tools and tests.  The kernel counts only when it is given the array's address,
+// and the launcher gives it only once pcfit_debug_qhull_reasons has been called in the process: the library's own
+// calls leave no trace in device globals.
+__device__ unsigned long long g_qhull_reason[16];
+static std::atomic<bool> g_qhull_counting{false};
+__device__ __forceinline__ void count_reason(unsigned long long *why, int k, unsigned long long by = 1ull)
+{
+    if (why) atomicAdd(&why[k], by);
+}
 // Optional phase timing (tools only; -DPCFIT_PHASE_CLOCK): thread 0 of one workgroup in 16 adds the clocks spent
 // between marks to g_qphase[k] (0 extremes, 1 simplex, 2 first partition, 3 placing, 4 the list's thread,
 // 5 partition of visible sets, 6 farthest points, 7 the end).
@@ -306,7 +316,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                                                          double *__restrict__ start_xy, int want_index,
                                                          const double *__restrict__ hull_x,
                                                          const double *__restrict__ hull_y,
-                                                         const int64_t *__restrict__ hull_idx)
+                                                         const int64_t *__restrict__ hull_idx,
+                                                         unsigned long long *__restrict__ why)
 {
     __shared__ Shared<QF, QT> S;
     const int64_t s = blockIdx.x, off = offsets[s];
@@ -324,7 +335,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         return;
     }
     if (m64 >= (1ll << 30) || n_hull[s] > QF - 2) {                // more facets at the end than there are slots
-        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[8], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; count_reason(why, 8); }
         return;
     }
     const int m = (int)m64;
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     __syncthreads();
     if (S.state == 2) {
-        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; count_reason(why, S.reason & 15); }
         return;
     }
     if (S.nvis == 1) {
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         }
         __syncthreads();
         if (S.state == 2) {
-            if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            if (tid == lt) { start[s] = QHULL_DEFER; count_reason(why, S.reason & 15); }
             return;
         }
     }
@@ -509,7 +520,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     }
     __syncthreads();
     if (S.state == 2) {
-        if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+        if (tid == lt) { start[s] = QHULL_DEFER; count_reason(why, S.reason & 15); }
         return;
     }
     ph.mark(1);
@@ -627,7 +638,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         }
         __syncthreads();
         if (S.state == 2) {
-            if (tid == lt) { start[s] = QHULL_DEFER; atomicAdd(&g_qhull_reason[S.reason & 15], 1ull); }
+            if (tid == lt) { start[s] = QHULL_DEFER; count_reason(why, S.reason & 15); }
             return;
         }
     }
@@ -968,9 +979,9 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 S.reason = 12;
         } else if (S.state == 0)
             S.reason = 13;
-        if (!answered) atomicAdd(&g_qhull_reason[S.reason & 15], 1ull);
-        atomicAdd(&g_qhull_reason[14], (unsigned long long)steps);
-        atomicAdd(&g_qhull_reason[15], visits);
+        if (!answered) count_reason(why, S.reason & 15);
+        count_reason(why, 14, (unsigned long long)steps);
+        count_reason(why, 15, visits);
         S.found = answered ? 0x7fffffff : -1;
     }
     __syncthreads();
@@ -1015,10 +1026,12 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
     const int form = forced ? forced : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;
     const dim3 grid((unsigned)n_slices);
     double2 *const pairs = reinterpret_cast<double2 *>(scratch);
+    unsigned long long *why = nullptr;
+    if (g_qhull_counting.load()) PCFIT_HIP(hipGetSymbolAddress(reinterpret_cast<void **>(&why), HIP_SYMBOL(g_qhull_reason)));
 #define PCFIT_QHULL_LAUNCH(QF, WG, QT)                                                                              \
     qhull_order_kernel<QF, WG, QT><<<grid, dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, pairs,     \
                                                               pairs + total, start, start_xy, want_index ? 1 : 0, \
-                                                              hull_x, hull_y, hull_idx)
+                                                              hull_x, hull_y, hull_idx, why)
     switch (form) {
     case 160: PCFIT_QHULL_LAUNCH(160, 5, 256); break;
     case 161: PCFIT_QHULL_LAUNCH(160, 8, 64); break;
@@ -1064,6 +1077,7 @@ PCFIT_API int pcfit_qhull_start_batch_dev(const double *ux, const double *uy, co
 PCFIT_API int pcfit_debug_qhull_reasons(int64_t *out16, int reset)
 {
     PCFIT_ENTER();
+    pcfit::g_qhull_counting.store(true);
     PCFIT_HIP(hipDeviceSynchronize());
     PCFIT_HIP(hipMemcpyFromSymbol(out16, HIP_SYMBOL(pcfit::g_qhull_reason), 16 * sizeof(int64_t)));
     if (reset) {

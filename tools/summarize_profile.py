@@ -25,7 +25,11 @@ for cname, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         per.setdefault(k, {})[cname] = sum(v) / len(v)
 with open(os.path.join(root, "profiles", f"{name}_pmc_hbm.csv"), "w", newline="") as f:
     csv.writer(f).writerows(out)
-traffic = {"note": "HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters, separate --pmc passes; gfx950 "
+sys.path.insert(0, root)
+from bench import kernel_sources_sha1
+traffic = {"source": [f"profiles/{name}_pmc_hbm.csv", f"profiles/{name}_bench_pmc_sq.csv"],
+           "kernel_sources_sha1": kernel_sources_sha1(),
+           "note": "HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters, separate --pmc passes; gfx950 "
                    "FETCH_SIZE reports half of a streaming read), bench.py --steps 3, 10000 slices x 8192 points",
            "algorithmic_bytes_per_launch": 10000 * 8192 * 16}
 for k, v in per.items():
@@ -33,5 +37,29 @@ for k, v in per.items():
         traffic["fit_residual_kernel_bytes"] = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
         traffic["fit_residual_kernel_fetch_KiB"] = v["FETCH_SIZE"]
         traffic["fit_residual_kernel_write_KiB"] = v["WRITE_SIZE"]
+# the SQ passes of the same run (tools/profile_bench.sh): one line per pass, counter and kernel, and the share of the
+# SIMDs' cycles in which the fused kernel issued a vector instruction
+sq = [["pass", "counter", "kernel", "dispatches", "mean"]]
+fused = {}
+for d in ("a", "b", "c"):
+    for f in glob.glob(os.path.join(src, "sq_" + d, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            agg[(r["Counter_Name"], r["Kernel_Name"][:60])].append(float(r["Counter_Value"]))
+        for (c, k), v in sorted(agg.items()):
+            sq.append([d, c, k, len(v), sum(v) / len(v)])
+            if "fit_residual_kernel" in k:
+                fused[c] = sum(v) / len(v)
+if len(sq) > 1:
+    with open(os.path.join(root, "profiles", f"{name}_bench_pmc_sq.csv"), "w", newline="") as f:
+        csv.writer(f).writerows(sq)
+if "SQ_ACTIVE_INST_VALU" in fused and "SQ_BUSY_CYCLES" in fused:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles of the SIMDs, SQ_BUSY_CYCLES the kernel's cycles summed over 32 shader
+    # engines; 1024 SIMDs: share = 4 * ACTIVE / (BUSY / 32 * 1024)
+    traffic["fit_residual_kernel_valu_issue_frac"] = fused["SQ_ACTIVE_INST_VALU"] / (8.0 * fused["SQ_BUSY_CYCLES"])
+    traffic["fit_residual_kernel_valu_insts_per_point"] = fused.get("SQ_INSTS_VALU", 0.0) * 64 / (10000 * 8192)
+bj = os.path.join(src, "bench.json")
+if os.path.exists(bj):
+    open(os.path.join(root, "profiles", f"{name}_bench.json"), "w").write(open(bj).read())
 json.dump(traffic, open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
 print(traffic)
