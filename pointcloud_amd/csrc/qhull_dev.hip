@@ -1017,10 +1017,13 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
                     const double *hull_y, const int64_t *hull_idx, bool want_index)
 {
     if (n_slices <= 0) return PCFIT_OK;
-    // The form with the fewest facet slots that holds every hull of the batch twice over (a slice that runs out of
-    // slots all the same is handed back): fewer slots, more slices in flight on a CU.
+    // The form with the fewest facet slots that holds the largest hull of the batch and two dozen facets more: the
+    // facets alive at a time are the edges of the polygon built so far, whose vertices are, but for a few that a later
+    // point takes out again, vertices of the hull (with 16 more than the hull no slice of the randomised sweeps ran out; one
+    // that runs out of slots all the same is handed back).  Fewer slots, more slices in flight on a compute unit.
     static const int forced = [] { const char *e = getenv("PCFIT_QHULL_FORM"); return e ? atoi(e) : 0; }();
-    const int64_t need = max_hull < 0 ? QF_MAX : 2 * max_hull + 16;
+    static const int margin = [] { const char *e = getenv("PCFIT_QHULL_MARGIN"); return e ? atoi(e) : 24; }();
+    const int64_t need = max_hull < 0 ? QF_MAX : max_hull + std::max(margin, 2);
     // (the forms of one wave per slice - 161, 225, 481 - measured slower at every batch size tried: they are kept
     // for PCFIT_QHULL_FORM only)
     const int form = forced ? forced : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;

@@ -1,7 +1,7 @@
 """Time of the device replay of Qhull's construction on slices of the bench's kind, with the number of insertions and
 of point visits it took and the slices it handed back, by cause (needs a GPU).
 python tools/exp_qhull_dev.py [slices] [points per slice] [x0 y0 (where the cylinder stands)] [decimals the coordinates
-are rounded to] [fraction of outliers]"""
+are rounded to, or - for none] [fraction of outliers]"""
 import ctypes as C
 import sys
 import time
@@ -27,7 +27,7 @@ r = 10 + 0.05 * torch.randn(S * n, dtype=torch.float64, device=dev)
 bad = torch.rand(S * n, device=dev) < (float(sys.argv[6]) if len(sys.argv) > 6 else 0.1)
 r = torch.where(bad, torch.rand(S * n, dtype=torch.float64, device=dev) * 14, r)
 x, y = shift[0] + r * torch.cos(th), shift[1] + r * torch.sin(th)
-decimals = int(sys.argv[5]) if len(sys.argv) > 5 else None          # coordinates as a text file with that many decimals holds them
+decimals = int(sys.argv[5]) if len(sys.argv) > 5 and sys.argv[5] != "-" else None          # coordinates as a text file with that many decimals holds them
 if decimals is not None:
     x, y = torch.round(x * 10 ** decimals) / 10 ** decimals, torch.round(y * 10 ** decimals) / 10 ** decimals
 off = torch.arange(S + 1, dtype=torch.int64, device=dev) * n
@@ -53,7 +53,8 @@ for rep in range(3):
     torch.cuda.synchronize()
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
     print(f"{e0.elapsed_time(e1):.3f} ms; per slice: {why[14] / S:.1f} insertions, {why[15] / S / n:.2f} visits per point after the "
-          f"first partition; handed back {int(why[:14].sum())} {why[:14].tolist()}; mean hull {float(nh.double().mean()):.1f}")
+          f"first partition; handed back {int(why[:14].sum())} {why[:14].tolist()}; mean hull {float(nh.double().mean()):.1f}, "
+          f"largest {int(nh.max())}")
 if PHASES:
     out = np.zeros(8, np.int64)
     L = F.lib()
