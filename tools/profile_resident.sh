@@ -3,7 +3,7 @@ set -e
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/resident
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/resident -o r --output-format csv -- python3 $R/tools/exp_resident.py ${1:-100000000} ${2:-2000} > $R/gpurun_out/resident/run.log 2>&1
+timeout -s KILL 500 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/resident -o r --output-format csv -- python3 $R/tools/exp_resident.py ${1:-100000000} ${2:-2000} ${3:-0.0} ${4:-qhull} > $R/gpurun_out/resident/run.log 2>&1
 tail -2 $R/gpurun_out/resident/run.log
 python3 - <<PY
 import csv
