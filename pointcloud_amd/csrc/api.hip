@@ -207,6 +207,29 @@ void pool_put(void *ptr, size_t bytes)
 }
 
 // ---- staged upload ----
+void *pinned_scratch(size_t bytes)
+{
+    static thread_local void *buf = nullptr;
+    static thread_local size_t cap = 0;
+    static const bool off = [] { const char *e = getenv("PCFIT_PINNED_SCRATCH"); return e && e[0] == '0'; }();
+    if (off) return nullptr;
+    if (bytes <= cap) return buf;
+    if (buf) {
+        (void)hipHostFree(buf);
+        buf = nullptr;
+        cap = 0;
+    }
+    size_t want = (size_t)1 << 20;
+    while (want < bytes) want <<= 1;
+    if (hipHostMalloc(&buf, want, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        buf = nullptr;
+        return nullptr;
+    }
+    cap = want;
+    return buf;
+}
+
 // hipMemcpy from pageable memory reaches about 30 GB/s on this platform, from pinned memory 56 GB/s; four
 // host threads that copy 8 MB chunks into pinned buffers and send each on a stream of their own reach
 // 40-50 GB/s from pageable memory.  Streams, events and the 64 MB of pinned buffers are made once per process

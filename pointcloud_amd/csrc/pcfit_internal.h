@@ -93,6 +93,10 @@ int pool_release();
 // buffers, each chunk followed by its own asynchronous transfer (api.hip).  Returns when the data is in place.
 int upload_staged(void *dst_dev, const void *src_host, size_t bytes);
 int download_staged(void *dst_host, const void *src_dev, size_t bytes);      // the same, the other way
+// Pinned host memory of the calling thread, at least `bytes` long (grown on demand, kept for the thread's life; null
+// when it cannot be had): small results copied into it arrive at the pinned rate and touch no fresh pages.  What
+// it held is gone after the next call from the same thread; the caller synchronises before it lets go of it.
+void *pinned_scratch(size_t bytes);
 constexpr size_t STAGED_UPLOAD_MIN = (size_t)32 << 20;
 
 // Device buffer that returns itself: the host-pointer entry points own all the

@@ -807,7 +807,20 @@ static int hybrid_core_impl(const double *dxp, const double *dyp, const int64_t 
     // Small per-slice arrays travel packed, one copy per stage and direction: every copy from or to
     // pageable memory is a blocking call of some tens of microseconds, more than the kernels of a small scan.
     auto up8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
-    std::vector<char> hbuf;
+    // host staging of the packed copies: the thread's pinned scratch (a vector when there is none)
+    struct HostStage {
+        std::vector<char> spare;
+        char *at = nullptr;
+        void resize(size_t n)
+        {
+            at = static_cast<char *>(pinned_scratch(n));
+            if (!at) {
+                spare.resize(n);
+                at = spare.data();
+            }
+        }
+        char *data() { return at; }
+    } hbuf;
 
     // 1. distinct points, rank check, hull
     // Qhull's order for every slice and nobody asks for the distinct points: the hull comes by the short route
