@@ -485,7 +485,10 @@ int pcfit_parse_xyz_text(const char *text, size_t n_bytes, int32_t n_threads, do
  * there (analyzer.py:236: what calculate_z_centers needs; both NaN if any z is
  * NaN, or if the scan is empty); pcfit_scan_hybrid_resident is
  * pcfit_scan_hybrid_batch on that copy; pcfit_scan_free releases it (to the
- * block cache).  A handle belongs to the device it was made on. */
+ * block cache).  A handle belongs to the device it was made on.  Beside the
+ * rows the handle keeps the z column by itself (8 bytes a point more): the
+ * count passes of the binning read it instead of the rows (24 bytes a point);
+ * PCFIT_SCAN_Z_COLUMN=0 in the environment, or too little memory, leaves it out. */
 typedef struct pcfit_scan pcfit_scan;
 int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan **scan, double *z_min_max);
 int pcfit_scan_free(pcfit_scan *scan);

@@ -580,6 +580,8 @@ PCFIT_API int pcfit_scan_upload_z_range(const double *xyz, int64_t n_points, dou
     PCFIT_HIP(hipGetDevice(&sc->device));
     PCFIT_TRY(upload_rows_in_z_range(xyz, n_points, z_lo, z_hi, sc->xyz, n_kept));
     sc->n_points = *n_kept;
+    PCFIT_TRY(scan_z_column(*sc, nullptr));
+    PCFIT_HIP(hipStreamSynchronize(nullptr));
     *scan = sc.release();
     return PCFIT_OK;
 }

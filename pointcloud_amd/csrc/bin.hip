@@ -59,13 +59,14 @@ struct BinGeom {
 struct BinSrc {
     const double *x, *y, *z;
     int64_t stride;
+    const double *zcol;            // z of point k at zcol[k] as well (nullable): the count pass reads this
 };
 // (x, y) of a row of a scan: 16 bytes at an address that is a multiple of 8, taken with one load
 struct __attribute__((packed, aligned(8))) BinRowXY {
     double x, y;
 };
 __device__ __forceinline__ bool is_rows(const BinSrc &src) { return src.stride == 3 && src.y == src.x + 1 && src.z == src.x + 2; }
-static BinSrc rows_of(const double *xyz) { return BinSrc{xyz, xyz + 1, xyz + 2, 3}; }
+static BinSrc rows_of(const double *xyz, const double *zcol = nullptr) { return BinSrc{xyz, xyz + 1, xyz + 2, 3, zcol}; }
 
 // Workgroups are handed to the 8 XCDs in turn (workgroup b runs on XCD b % 8) and every XCD has its own L2.
 // Consecutive chunks write neighbouring parts of every window's output, often parts of the same cache line; with
@@ -148,13 +149,16 @@ __global__ __launch_bounds__(64) void bin_count_kernel(BinSrc src, int64_t n, in
         lhist[s] = 0;
     __syncthreads();
     const int64_t begin = c * chunk_len, end = min(n, begin + chunk_len);
+    // (the z column by itself when the scan has one: 8 bytes a point instead of the 24 of a row)
+    const double *zsrc = src.zcol ? src.zcol : src.z;
+    const int64_t zstride = src.zcol ? 1 : src.stride;
     // BIN_UNROLL loads of z in flight per lane: one wave per chunk has nothing else to hide the latency with
     for (int64_t base = begin + threadIdx.x; base < end; base += 64 * BIN_UNROLL) {
         double z[BIN_UNROLL];
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
             const int64_t i = base + 64 * u;
-            z[u] = i < end ? src.z[i * src.stride] : __longlong_as_double(0x7ff8000000000000ll);   // NaN: no window
+            z[u] = i < end ? zsrc[i * zstride] : __longlong_as_double(0x7ff8000000000000ll);   // NaN: no window
         }
 #pragma unroll
         for (int u = 0; u < BIN_UNROLL; u++) {
@@ -1035,7 +1039,7 @@ constexpr int64_t BIN_L2_CHUNK = 4096;       // entries per level-2 workgroup
 // result - members, order, bytes - is that of the single pass.
 static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                          bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
-                         DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st)
+                         DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st, const double *dz)
 {
     const int wshift = S <= 4096 ? 6 : 7;
     const int64_t W = 1ll << wshift, G = ((S - 1) >> wshift) + 1;
@@ -1043,7 +1047,7 @@ static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_l
     PCFIT_TRY(bin_check_windows(z_lo, z_hi, S, geom));
     BinGeom g;
     PCFIT_TRY(bin_geom(geom, S, g));
-    const BinSrc rows = rows_of(dxyz);
+    const BinSrc rows = rows_of(dxyz, dz);
     // level 1
     const BinPlan p1 = bin_plan(n_points, G);
     DevBuf dgoff, dws1, x1, y1, k1, i1;
@@ -1115,10 +1119,10 @@ static int bin_two_level(const double *dxyz, int64_t n_points, const double *z_l
 // as one pass would give.
 static int bin_in_runs(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                        bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
-                       DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st)
+                       DevBuf &dperm, const DevBuf &dlo, const DevBuf &dhi, hipStream_t st, const double *dz)
 {
     const int64_t W = BIN_MAX_SLICES, G = (S + W - 1) / W;
-    const BinSrc rows = rows_of(dxyz);
+    const BinSrc rows = rows_of(dxyz, dz);
     std::vector<DevBuf> ws((size_t)G), off((size_t)G);
     std::vector<double> geom((size_t)G * 3);
     std::vector<int64_t> hoff;
@@ -1162,7 +1166,7 @@ static int bin_in_runs(const double *dxyz, int64_t n_points, const double *z_lo,
 // With capacity >= 0 and more members than that, only the offsets are produced.
 int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                   bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
-                  DevBuf &dperm, hipStream_t st)
+                  DevBuf &dperm, hipStream_t st, const double *dz)
 {
     PCFIT_REQUIRE(n_points >= 0 && S >= 1, "bin: need n_points >= 0 and n_slices >= 1");
     PCFIT_REQUIRE(z_lo && z_hi && offsets, "bin: null pointer");
@@ -1175,14 +1179,14 @@ int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, cons
     PCFIT_TRY(doff.alloc((size_t)(S + 1) * 8));
     if (S > BIN_MAX_SLICES)
         return bin_in_runs(dxyz, n_points, z_lo, z_hi, S, want_perm, capacity, offsets, doff, dx, dy, dperm, dlo, dhi,
-                           st);
+                           st, dz);
     // (read at every call so that a test can switch between the two forms; negative = never)
     const char *env = getenv("PCFIT_BIN_TWO_LEVEL_MIN");
     const int64_t two_level_min = env ? atoll(env) : BIN_TWO_LEVEL_MIN;
     if (S > BIN_STG_MAX_SLICES && two_level_min >= 0 && n_points >= two_level_min)
         return bin_two_level(dxyz, n_points, z_lo, z_hi, S, want_perm, capacity, offsets, doff, dx, dy, dperm, dlo,
-                             dhi, st);
-    const BinSrc rows = rows_of(dxyz);
+                             dhi, st, dz);
+    const BinSrc rows = rows_of(dxyz, dz);
     PCFIT_TRY(dws.alloc(bin_plan(n_points, S).bytes));
     PCFIT_TRY(count_launch(rows, n_points, dlo.as<double>(), dhi.as<double>(), S, geom, doff.as<int64_t>(), dws.p,
                            dws.bytes, st));
@@ -1342,17 +1346,41 @@ PCFIT_API int pcfit_bin2_scatter_dev(int64_t n_points, int64_t n_slices, const d
                                   as_stream(stream));
 }
 
+namespace pcfit {
+
+__global__ __launch_bounds__(256) void z_column_kernel(const double *__restrict__ xyz, int64_t n, double *__restrict__ z)
+{
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        z[i] = xyz[3 * i + 2];
+}
+
+int scan_z_column(pcfit_scan &scan, hipStream_t st)
+{
+    const char *env = getenv("PCFIT_SCAN_Z_COLUMN");
+    if ((env && env[0] == '0') || scan.n_points <= 0) return PCFIT_OK;
+    if (scan.z.alloc((size_t)scan.n_points * 8) != PCFIT_OK) {
+        (void)hipGetLastError();               // (memory is short: the count passes read the rows)
+        return PCFIT_OK;
+    }
+    const int64_t blocks = std::min<int64_t>(8192, (scan.n_points + 255) / 256);
+    z_column_kernel<<<dim3((unsigned)blocks), dim3(256), 0, st>>>(scan.xyz.as<double>(), scan.n_points, scan.z.as<double>());
+    PCFIT_LAUNCH_CHECK();
+    return PCFIT_OK;
+}
+
+}  // namespace pcfit
+
 // bin on the device, slices to the host: the scan is on the device already
 static int bin_resident(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
                         int64_t *offsets, double *x_out, double *y_out, int64_t *perm, int64_t capacity,
-                        int64_t *total)
+                        int64_t *total, const double *dz = nullptr)
 {
     PCFIT_REQUIRE(total, "bin: null pointer");
     hipStream_t st = nullptr;
     DevBuf doff, dx, dy, dperm;
     const int64_t room = (x_out == nullptr || y_out == nullptr) ? 0 : std::max<int64_t>(capacity, 0);
     PCFIT_TRY(bin_on_device(dxyz, n_points, z_lo, z_hi, n_slices, perm != nullptr, room, offsets, doff, dx, dy, dperm,
-                            st));
+                            st, dz));
     *total = offsets[n_slices];
     if (*total > room) {
         set_error("bin: outputs hold %lld points, %lld needed", (long long)capacity, (long long)*total);
@@ -1387,7 +1415,7 @@ PCFIT_API int pcfit_scan_bin_slices(const pcfit_scan *scan, const double *z_lo, 
     PCFIT_HIP(hipGetDevice(&dev));
     PCFIT_REQUIRE(dev == scan->device, "bin: the scan lives on device %d, the current device is %d", scan->device, dev);
     return bin_resident(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, offsets, x_out, y_out, perm,
-                        capacity, total);
+                        capacity, total, scan->z.as<double>());
 }
 
 // members per window of the resident scan: the count pass alone
@@ -1412,8 +1440,9 @@ PCFIT_API int pcfit_scan_window_counts(const pcfit_scan *scan, const double *z_l
         PCFIT_TRY(bin_check_windows(z_lo + s0, z_hi + s0, Sg, geom));
         PCFIT_TRY(doff.alloc((size_t)(Sg + 1) * 8));
         PCFIT_TRY(dws.alloc(pcfit_bin_workspace_bytes(scan->n_points, Sg)));
-        PCFIT_TRY(pcfit_bin_count_dev(scan->xyz.as<double>(), scan->n_points, dlo.as<double>() + s0,
-                                      dhi.as<double>() + s0, Sg, geom, doff.as<int64_t>(), dws.p, dws.bytes, st));
+        PCFIT_TRY(count_launch(rows_of(scan->xyz.as<double>(), scan->z.as<double>()), scan->n_points,
+                               dlo.as<double>() + s0, dhi.as<double>() + s0, Sg, geom, doff.as<int64_t>(), dws.p, dws.bytes,
+                               st));
         off.resize((size_t)Sg + 1);
         PCFIT_TRY(doff.download(off.data(), off.size() * 8, st));
         PCFIT_HIP(hipStreamSynchronize(st));

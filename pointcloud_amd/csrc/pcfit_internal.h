@@ -136,15 +136,21 @@ struct DevBuf {
 // bin.hip: the scan (rows of xyz on the device) binned into the windows - offsets to the host and to doff,
 // x, y (and perm) left on the device; in two levels when the windows are many.  With capacity >= 0 and more
 // members than that only the offsets are produced.
+// dz (nullable): the scan's z column by itself; the count passes then read it instead of the rows.
 int bin_on_device(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t n_slices,
                   bool want_perm, int64_t capacity, int64_t *offsets, DevBuf &doff, DevBuf &dx, DevBuf &dy,
-                  DevBuf &dperm, hipStream_t st);
+                  DevBuf &dperm, hipStream_t st, const double *dz = nullptr);
+// the z column of a scan of rows (xyz -> z), enqueued; scan_z_column: for a scan just uploaded (an empty column and
+// PCFIT_OK when it is switched off by PCFIT_SCAN_Z_COLUMN=0 or memory is short)
+int scan_z_column(pcfit_scan &scan, hipStream_t st);
 
 }  // namespace pcfit
 
 // A scan kept on the device between calls (the opaque pcfit_scan of the header).
 struct pcfit_scan {
     pcfit::DevBuf xyz;
+    pcfit::DevBuf z;               // the z column by itself (8 bytes a point; empty when it was not made): what the
+                                   // count passes of the binning read instead of the rows
     int64_t n_points = 0;
     int device = 0;
 };

@@ -1134,7 +1134,7 @@ __global__ __launch_bounds__(64) void z_range_final_kernel(const double *__restr
 }
 
 // bin the resident scan into the windows and run the chain on the slices
-static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
+static int scan_hybrid(const double *dxyz, const double *dz, int64_t n_points, const double *z_lo, const double *z_hi, int64_t S,
                        double inlier_tol, int32_t max_trials, double min_inliers_frac, const double *r_range,
                        double huber_delta, int32_t use_hull, int32_t hull_order, uint64_t seed, int64_t *offsets,
                        int32_t *status, double *fit, int64_t *n_unique, int64_t *cand_offsets, double *cand_x,
@@ -1150,7 +1150,7 @@ static int scan_hybrid(const double *dxyz, int64_t n_points, const double *z_lo,
                   "scan_hybrid: null pointer");
     PCFIT_REQUIRE(max_trials >= 0, "scan_hybrid: max_trials negative");
     DevBuf doff, dx, dy, dperm;
-    PCFIT_TRY(bin_on_device(dxyz, n_points, z_lo, z_hi, S, false, -1, offsets, doff, dx, dy, dperm, st));
+    PCFIT_TRY(bin_on_device(dxyz, n_points, z_lo, z_hi, S, false, -1, offsets, doff, dx, dy, dperm, st, dz));
     int64_t total, max_len;
     PCFIT_TRY(check_offsets(offsets, S, &total, &max_len));
     return hybrid_core(dx.as<double>(), dy.as<double>(), doff.as<int64_t>(), offsets, S, total, max_len, inlier_tol,
@@ -1175,7 +1175,7 @@ PCFIT_API int pcfit_scan_hybrid_batch(const double *xyz, int64_t n_points, const
     hipStream_t st = nullptr;
     DevBuf dxyz;                   // the scan goes to the device once; slices are formed and stay there
     PCFIT_TRY(dxyz.upload(xyz, (size_t)n_points * 24, st));
-    return scan_hybrid(dxyz.as<double>(), n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials, min_inliers_frac,
+    return scan_hybrid(dxyz.as<double>(), nullptr, n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials, min_inliers_frac,
                        r_range, huber_delta, use_hull, hull_order, seed, offsets, status, fit, n_unique, cand_offsets,
                        cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len, cand_capacity,
                        st);
@@ -1208,6 +1208,7 @@ PCFIT_API int pcfit_scan_upload(const double *xyz, int64_t n_points, pcfit_scan 
             PCFIT_TRY(out.download(z_min_max, 16, st));
         }
     }
+    PCFIT_TRY(scan_z_column(*sc, st));
     PCFIT_HIP(hipStreamSynchronize(st));
     *scan = sc.release();
     return PCFIT_OK;
@@ -1235,7 +1236,7 @@ PCFIT_API int pcfit_scan_hybrid_resident(const pcfit_scan *scan, const double *z
     PCFIT_HIP(hipGetDevice(&dev));
     PCFIT_REQUIRE(dev == scan->device, "scan_hybrid: the scan lives on device %d, the current device is %d",
                   scan->device, dev);
-    return scan_hybrid(scan->xyz.as<double>(), scan->n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials,
+    return scan_hybrid(scan->xyz.as<double>(), scan->z.as<double>(), scan->n_points, z_lo, z_hi, n_slices, inlier_tol, max_trials,
                        min_inliers_frac, r_range, huber_delta, use_hull, hull_order, seed, offsets, status, fit, n_unique,
                        cand_offsets, cand_x, cand_y, mask, radius, theta, argmax_argmin, ov_scal, dev_uniform, grid_len,
                        cand_capacity, nullptr);
