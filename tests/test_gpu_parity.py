@@ -439,6 +439,34 @@ def test_bin_slices_stable_and_exact():
     assert np.array_equal(x, q[perm, 0]) and np.array_equal(y, q[perm, 1])
 
 
+def test_resident_scan_with_and_without_its_z_column():
+    """A resident scan keeps its z column beside the rows and the count passes of the binning read that; with
+    PCFIT_SCAN_Z_COLUMN=0 they read the rows: same offsets, members and order either way, in one level and in two,
+    with z on shared window edges and NaN among it (analyzer.py:49-52)."""
+    from pointcloud_amd import DeviceScan
+    gen = np.random.default_rng(77)
+    pts = gen.random((400_000, 3))
+    pts[:, 2] = np.round(pts[:, 2] * 700.0 * 4.0) / 4.0 * 0.125
+    pts[::997, 2] = np.nan
+    lo = 0.125 * np.arange(700)
+    hi = lo + 0.125
+    got = {}
+    for column in ("1", "0"):
+        for two_level_from in ("-1", "0"):
+            os.environ["PCFIT_SCAN_Z_COLUMN"] = column
+            os.environ["PCFIT_BIN_TWO_LEVEL_MIN"] = two_level_from
+            try:
+                with DeviceScan(pts) as scan:
+                    got[column, two_level_from] = F.bin_slices(scan, lo, hi) + (scan.window_counts(lo, hi),)
+            finally:
+                del os.environ["PCFIT_SCAN_Z_COLUMN"], os.environ["PCFIT_BIN_TWO_LEVEL_MIN"]
+    o_ref, p_ref = N.bin_slices(pts, lo, hi)
+    for key, (off, x, y, perm, counts) in got.items():
+        assert np.array_equal(off, o_ref) and np.array_equal(perm, p_ref), key
+        assert np.array_equal(x, pts[perm, 0]) and np.array_equal(y, pts[perm, 1]), key
+        assert np.array_equal(counts, np.diff(o_ref)), key
+
+
 def test_two_level_binning_on_the_device_without_a_read_back():
     """pcfit_bin2_count_dev / pcfit_bin2_scatter_dev: members, order and bytes of the CPU's binning for 2000 windows
     with gaps, 700 windows sharing edges with z on a grid that hits them (also the edges between groups of 64), and
