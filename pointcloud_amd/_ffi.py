@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -123,6 +124,13 @@ def lib():
             raise PcfitError(
                 f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); this package has no CPU fallback")
+        # Where PyTorch is installed its HIP runtime has to be the first one in the process: loaded after this
+        # library's, torch finds no GPU ("No HIP GPUs are available"); loaded before, both share it.  So torch is
+        # imported here first when it is there and has not been yet (PCFIT_TORCH_FIRST=0 leaves that out).
+        if "torch" not in sys.modules and os.environ.get("PCFIT_TORCH_FIRST", "1") != "0":
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
