@@ -4,11 +4,13 @@
 // sets of visible facets among the two new facets, and the search of every set's farthest point - runs
 // across the workgroup.  The order of the points inside an outside set is not kept (it decides nothing but ties).
 // The kernel follows the host replay decision for decision.  Points that lie below both new facets of an
-// insertion by less than a roundoff unit are listed during the parallel pass and taken through Qhull's horizon
-// search by the one thread afterwards (whatever mode Qhull's search is in by then, it ends in that walk).  Where
-// the order inside a set would matter - two points tie for the farthest of a set, a point lies 4 to 8 roundoff
-// units above the first new facet, two facets get their first point through the horizon search in one
-// insertion - or one of the fixed capacities below runs out, or the replay ends with more vertices than
+// insertion by less than a roundoff unit go through Qhull's horizon search (whatever mode Qhull's search is in by
+// then, it ends in that walk): their wave walks it during the parallel pass, and the few that end outside of a
+// facet are listed and placed by the one thread afterwards.  In the first partition the points arrive in the order
+// of the sorted distinct array, so of two points that tie for the farthest of a set the lexicographically first is
+// Qhull's.  Where the order inside a later set would matter - two points tie for the farthest of a set, a point lies
+// 4 to 8 roundoff units above the first new facet, two facets get their first point through the horizon search in
+// one insertion - or one of the fixed capacities below runs out, or the replay ends with more vertices than
 // the exact hull has, the slice is handed back (start = QHULL_DEFER) and the host replay decides it.
 #include <stdlib.h>
 
@@ -75,6 +77,17 @@ struct Far {
         if (!has || o.d > d) *this = o;
         else if (o.d == d && (o.x != x || o.y != y)) tie = 1;
     }
+    // The same where the points arrive in the order of the sorted distinct array, whatever order they are read in
+    // (Qhull's first partition): of two points at the greatest distance the lexicographically first is the one
+    // Qhull met first, and it keeps the first.
+    __device__ __forceinline__ void take_first(double od, double ox, double oy)
+    {
+        if (!has || od > d || (od == d && (ox < x || (ox == x && oy < y)))) { d = od; x = ox; y = oy; has = 1; tie = 0; }
+    }
+    __device__ __forceinline__ void join_first(const Far &o)
+    {
+        if (o.has) take_first(o.d, o.x, o.y);
+    }
 };
 template <int QF, int QT>
 struct Shared {
@@ -98,6 +111,8 @@ struct Shared {
     double unc_d[QU], unc_x[QU], unc_y[QU];
     unsigned short visit[QF], visit_id;
     short copl[64];
+    unsigned wave_seen[QT / 64][(QF + 31) / 32];     // wave_horizon's visit marks and stack, one set per wave
+    short wave_copl[QT / 64][16];
     double red_d[QT / 64];
     int red_i[QT / 64];
     double ext_k1[4][QT / 64], ext_k2[4][QT / 64];
@@ -232,12 +247,26 @@ __device__ __forceinline__ double lane_value(double v, int lane)
 {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+template <bool FIRST = false>
 __device__ __forceinline__ void far_fold(Far &f)
 {
     const double top = wave_max(f.has ? f.d : -1.0);            // (distances of outside points are positive)
     const unsigned long long best = __builtin_amdgcn_ballot_w64(f.has && f.d == top);
     if (best == 0ull) {
         f.has = 0;
+        return;
+    }
+    if constexpr (FIRST) {
+        // the lexicographically first of the points at that distance
+        const bool holds = f.has && f.d == top;
+        const double big = 1.7976931348623157e308;
+        const double bx = -wave_max(holds ? -f.x : -big);
+        const double by = -wave_max(holds && f.x == bx ? -f.y : -big);
+        f.d = top;
+        f.x = bx;
+        f.y = by;
+        f.has = 1;
+        f.tie = 0;
         return;
     }
     const int lane = (int)__builtin_ctzll(best);
@@ -252,13 +281,13 @@ __device__ __forceinline__ void far_fold(Far &f)
 // The farthest points of two sets over what every thread has seen, to every thread; `flag` comes back as the "or"
 // of every thread's.  One barrier: the partials of the last call were read before the barrier that every caller
 // passes between two calls.
-template <class SH>
+template <bool FIRST = false, class SH>
 __device__ void block_far(SH &S, Far &f0, Far &f1, bool &flag)
 {
     constexpr int QT = SH::THREADS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    far_fold(f0);
-    far_fold(f1);
+    far_fold<FIRST>(f0);
+    far_fold<FIRST>(f1);
     const bool wave_flag = __builtin_amdgcn_ballot_w64(flag) != 0ull;
     if (lane == 0) {
         S.wave_far[0][wave] = f0;
@@ -270,8 +299,13 @@ __device__ void block_far(SH &S, Far &f0, Far &f1, bool &flag)
     f0.has = f1.has = 0;
     for (int w = 0; w < QT / 64; w++) {
         flag = flag || S.wave_flag[w] != 0;
-        f0.join(S.wave_far[0][w]);
-        f1.join(S.wave_far[1][w]);
+        if constexpr (FIRST) {
+            f0.join_first(S.wave_far[0][w]);
+            f1.join_first(S.wave_far[1][w]);
+        } else {
+            f0.join(S.wave_far[0][w]);
+            f1.join(S.wave_far[1][w]);
+        }
     }
 }
 
@@ -299,6 +333,45 @@ __device__ __forceinline__ void wave_slots(int *counter, const bool (&mine)[U], 
         slot[u] = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(votes[u] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)votes[u], 0u));
         base += __popcll(votes[u]);
     }
+}
+
+// qh_findbesthorizon for one point, by a whole wave at once (every lane holds the same point and does the same
+// steps; the marks and the stack are the wave's own): the greatest distance the walk meets, from facet `from` at
+// distance `bestdist` on.  The facet structure is only read.  False when the walk's stack ran out.
+template <class SH>
+__device__ __attribute__((noinline)) bool wave_horizon(SH &S, int wave, int from, double px, double py, double searchdist, double &bestdist)
+{
+    constexpr int WORDS = (SH::FACETS + 31) / 32;
+    unsigned *seen = S.wave_seen[wave];
+    short *copl = S.wave_copl[wave];
+    for (int k = threadIdx.x & 63; k < WORDS; k += 64) seen[k] = 0u;
+    double minsearch = bestdist - searchdist;
+    int facet = from, nextfacet = 0, size = 0;
+    seen[from >> 5] |= 1u << (from & 31);
+    while (true) {
+        for (int j = 0; j < 2; j++) {
+            const int nb = j ? S.nb1[facet] : S.nb0[facet];
+            if (((seen[nb >> 5] >> (nb & 31)) & 1u) || S.visible[nb]) continue;
+            seen[nb >> 5] |= 1u << (nb & 31);
+            const double d = plane_dist(S, nb, px, py);
+            if (d > bestdist) {
+                minsearch = d - searchdist;
+                if (d > bestdist + searchdist) size = 0;
+                bestdist = d;
+            } else if (d < minsearch)
+                continue;
+            if (nextfacet) {
+                if (size == 16) return false;
+                copl[size++] = (short)nextfacet;
+            }
+            nextfacet = nb;
+        }
+        facet = nextfacet;
+        if (facet) nextfacet = 0;
+        else if (size == 0) break;
+        else facet = copl[--size];
+    }
+    return true;
 }
 
 // QF: facet slots (the LDS a workgroup takes grows with them, and the workgroups a CU holds shrink: every phase of
@@ -574,7 +647,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 cls[u] = c;
 #pragma unroll
                 for (int k = 0; k < 3; k++)
-                    if (c == k) far[k].take(d, px[u], py[u]);
+                    if (c == k) far[k].take_first(d, px[u], py[u]);
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -606,16 +679,15 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         // the farthest point of each of the three sets
         Far unused = {0.0, 0.0, 0.0, 0, 0};
         bool none = false;
-        block_far(S, far[0], far[1], none);
+        block_far<true>(S, far[0], far[1], none);
         __syncthreads();                           // (the partials are read: they may be written again)
-        block_far(S, far[2], unused, none);
+        block_far<true>(S, far[2], unused, none);
         if (tid == lt) {
             const int cnt[3] = {S.c0[0], S.c0[1], S.c0[2]};
             const int fs[3] = {f0, f1, f2};
             const unsigned at[3] = {0u, (unsigned)(m - cnt[1]), 0x80000000u | (unsigned)m};
             S.gap_lo = cnt[0];
             for (int c = 0; c < 3; c++) {
-                if (far[c].has && far[c].tie) { S.state = 2; S.reason = 4; }
                 S.total[fs[c]] = cnt[c];
                 S.far_x[fs[c]] = far[c].x;
                 S.far_y[fs[c]] = far[c].y;
@@ -737,6 +809,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         const int nvis = S.nvis, a0 = S.newf[0], a1 = S.newf[1], gap_lo = S.gap_lo;
         const double apex_x = uni(S.apex_x), apex_y = uni(S.apex_y);
         const double minoutside = uni(S.thr[2]), reach = uni(S.thr[3]), distround = uni(S.thr[0]);
+        const double searchdist = distround * 2 + uni(S.thr[1]);
         const double a0_n0 = uni(S.n0[a0]), a0_n1 = uni(S.n1[a0]), a0_off = uni(S.off[a0]);
         const double a1_n0 = uni(S.n0[a1]), a1_n1 = uni(S.n1[a1]), a1_off = uni(S.off[a1]);
         Far far0 = {0.0, 0.0, 0.0, 0, 0}, far1 = far0;
@@ -766,11 +839,12 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 to_at[u] = to_lo | (from << 31);
                 to_end[u] = to_lo + cnt - 1;
             }
-            int cls[4];
+            int cls[4], near_bits = 0;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 int c = 2;
                 double d = 0.0;
+                bool near = false;
                 if (px[u] != apex_x || py[u] != apex_y) {
                     d = a0_off + px[u] * a0_n0 + py[u] * a0_n1;
                     if (d >= minoutside) {
@@ -780,22 +854,14 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                         const double d0 = d;
                         d = a1_off + px[u] * a1_n0 + py[u] * a1_n1;
                         if (d >= minoutside) c = 1;
-                        else if (fmax(d0, d) >= -distround) {
-                            // below both by less than a roundoff unit: the horizon search, after the pass
-                            const int at = atomicAdd(&S.n_unc, 1);
-                            if (at < QU) {
-                                S.unc_x[at] = px[u];
-                                S.unc_y[at] = py[u];
-                                S.unc_slot[at] = S.pt_slot[piece[u]];
-                                S.unc_from[at] = d > d0 ? a1 : a0;
-                                S.unc_d[at] = fmax(d0, d);
-                            }
-                        }
+                        else if (fmax(d0, d) >= -distround)
+                            near = true;            // below both by less than a roundoff unit: the horizon search
                     }
                 }
                 cls[u] = c;
                 if (c == 0) far0.take(d, px[u], py[u]);
                 else if (c == 1) far1.take(d, px[u], py[u]);
+                if (near) near_bits |= 1 << u;
             }
             // the points of the first new facet upwards from their piece's start, those of the second downwards from
             // its end; a wave's points of one turn lie in consecutive pieces (one, as a rule)
@@ -813,6 +879,34 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                     double2 *dst = to_at[u] < 0 ? bufs0 : bufs1;
                     if (m0[u]) dst[(to_at[u] & (int)IDX_MASK) + s0[u]] = make_double2(px[u], py[u]);
                     if (m1[u]) dst[to_end[u] - s1[u]] = make_double2(px[u], py[u]);
+                }
+            }
+            // Points below both new facets by less than a roundoff unit are many where coordinates were rounded (points
+            // in line with the new facets) and nearly all of them end outside of nothing.  The wave walks the horizon
+            // for each, one after the other, and only those that did get outside of a facet are listed for the
+            // thread that keeps the list, which walks again and places them after the pass.
+            if (__builtin_amdgcn_ballot_w64(near_bits != 0) != 0ull) {
+                for (int u = 0; u < 4; u++) {
+                    unsigned long long todo = __builtin_amdgcn_ballot_w64((near_bits >> u) & 1);
+                    while (todo) {
+                        const int src = (int)__builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        const double wx = lane_value(px[u], src), wy = lane_value(py[u], src);
+                        const double d0 = a0_off + wx * a0_n0 + wy * a0_n1, d1 = a1_off + wx * a1_n0 + wy * a1_n1;
+                        const int from = d1 > d0 ? a1 : a0;
+                        double best = fmax(d0, d1);
+                        const bool walked = wave_horizon(S, tid >> 6, from, wx, wy, searchdist, best);
+                        if ((tid & 63) == src && (!walked || best >= minoutside)) {
+                            const int at = atomicAdd(&S.n_unc, 1);
+                            if (at < QU) {
+                                S.unc_x[at] = wx;
+                                S.unc_y[at] = wy;
+                                S.unc_slot[at] = S.pt_slot[piece[u]];
+                                S.unc_from[at] = from;
+                                S.unc_d[at] = fmax(d0, d1);
+                            }
+                        }
+                    }
                 }
             }
         }
