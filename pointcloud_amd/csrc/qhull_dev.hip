@@ -1115,18 +1115,33 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
     // facets alive at a time are the edges of the polygon built so far, whose vertices are, but for a few that a later
     // point takes out again, vertices of the hull (with 16 more than the hull no slice of the randomised sweeps ran out; one
     // that runs out of slots all the same is handed back).  Fewer slots, more slices in flight on a compute unit.
-    static const int forced = [] { const char *e = getenv("PCFIT_QHULL_FORM"); return e ? atoi(e) : 0; }();
+    // PCFIT_QHULL_FORM (tools and tests; read at every call) names a form: slots + 0 / 1 / 2 / 3 for 256 / 64 / 512 /
+    // 128 threads.
+    const char *env_form = getenv("PCFIT_QHULL_FORM");
+    const int forced = env_form ? atoi(env_form) : 0;
     static const int margin = [] { const char *e = getenv("PCFIT_QHULL_MARGIN"); return e ? atoi(e) : 24; }();
     const int64_t need = max_hull < 0 ? QF_MAX : max_hull + std::max(margin, 2);
-    // (the forms of one wave per slice - 161, 225, 481 - measured slower at every batch size tried: they are kept
-    // for PCFIT_QHULL_FORM only)
+    // A slice's construction is a chain of short phases (0.7 ms of dependent latency for a slice of 50 000 points
+    // however many threads work on it), so what fills the chip is the number of slices in flight, and the LDS of the
+    // facet slots is what limits it: 5 slices to a compute unit in workgroups of 256 threads (registers), 8 of 128
+    // threads and 10 of 64 with 96 slots, 7 with 128 slots, 6 with 160 whatever the threads.  Measured on 96 slots,
+    // slices of 5000 to 100 000 points: up to 5 slices a compute unit 256 threads win (1000 x 100 000: 1.94 ms
+    // against 2.09 with 128), up to a dozen 128 threads (2000 x 50 000: 1.77 against 2.45 with 256, 1.85 with 64),
+    // beyond that one wave a slice (10 000 x 8192: 2.03 against 2.39 and 3.70; 20 000 x 5000: 2.67, 3.49, 5.57).
+    // With 160 slots and more the narrow forms gain nothing (six slices to a compute unit against five).
     // Few long slices (a scan cut into some dozen windows): a slice's passes are chains of turns of one point a
     // thread, each a trip to memory long, and with no more slices than compute units there is nothing to fill the
-    // chip with but threads - workgroups of 512 then (forms 162, 226, 482).  Measured on 57 to 256 slices of 50 000
-    // to 1 000 000 points: 5 to 40 % faster than with 256 threads (1024 threads gain less: sixteen waves wait for
-    // the slowest at every barrier); from 400 slices on the narrow form wins.
+    // chip with but threads - workgroups of 512 then.  Measured on 57 to 256 slices of 50 000 to 1 000 000 points:
+    // 5 to 40 % faster than with 256 threads (1024 threads gain less: sixteen waves wait for the slowest at every
+    // barrier); from 400 slices on the narrow form wins.
+    int dev = 0, cus = 256;
+    PCFIT_HIP(hipGetDevice(&dev));
+    PCFIT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const int slots = need <= 96 ? 96 : need <= 128 ? 128 : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;
     const bool wide = n_slices <= 256 && total / n_slices >= 32768;
-    const int form = forced ? forced : (need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX) + (wide ? 2 : 0);
+    const int64_t per_cu = (n_slices + cus - 1) / std::max(cus, 1);
+    const int threads = wide ? 2 : (slots > 128 || per_cu <= 5) ? 0 : per_cu <= 12 ? 3 : 1;
+    const int form = forced ? forced : slots + threads;
     const dim3 grid((unsigned)n_slices);
     double2 *const pairs = reinterpret_cast<double2 *>(scratch);
     unsigned long long *why = nullptr;
@@ -1136,14 +1151,24 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
                                                               pairs + total, start, start_xy, want_index ? 1 : 0, \
                                                               hull_x, hull_y, hull_idx, why)
     switch (form) {
+    case 96: PCFIT_QHULL_LAUNCH(96, 5, 256); break;
+    case 97: PCFIT_QHULL_LAUNCH(96, 10, 64); break;
+    case 98: PCFIT_QHULL_LAUNCH(96, 2, 512); break;
+    case 99: PCFIT_QHULL_LAUNCH(96, 8, 128); break;
+    case 128: PCFIT_QHULL_LAUNCH(128, 5, 256); break;
+    case 129: PCFIT_QHULL_LAUNCH(128, 8, 64); break;
+    case 130: PCFIT_QHULL_LAUNCH(128, 2, 512); break;
+    case 131: PCFIT_QHULL_LAUNCH(128, 7, 128); break;
     case 160: PCFIT_QHULL_LAUNCH(160, 5, 256); break;
     case 161: PCFIT_QHULL_LAUNCH(160, 8, 64); break;
     case 162: PCFIT_QHULL_LAUNCH(160, 2, 512); break;
+    case 163: PCFIT_QHULL_LAUNCH(160, 6, 128); break;
     case 224: PCFIT_QHULL_LAUNCH(224, 5, 256); break;
-    case 226: PCFIT_QHULL_LAUNCH(224, 2, 512); break;
-    case QF_MAX + 2: PCFIT_QHULL_LAUNCH(QF_MAX, 2, 512); break;
     case 225: PCFIT_QHULL_LAUNCH(224, 6, 64); break;
+    case 226: PCFIT_QHULL_LAUNCH(224, 2, 512); break;
+    case 227: PCFIT_QHULL_LAUNCH(224, 4, 128); break;
     case QF_MAX + 1: PCFIT_QHULL_LAUNCH(QF_MAX, 3, 64); break;
+    case QF_MAX + 2: PCFIT_QHULL_LAUNCH(QF_MAX, 2, 512); break;
     default: PCFIT_QHULL_LAUNCH(QF_MAX, 3, 256); break;
     }
 #undef PCFIT_QHULL_LAUNCH

@@ -227,6 +227,20 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
         assert both.sum() > 600 and np.array_equal(again[both], got[both]), (max_hull, np.flatnonzero(again != got)[:5])
         if max_hull < 0:                          # the same form: the same slices handed back
             assert np.array_equal(again, got)
+    # ... the narrow and the wide ones too, which the library picks by the number of slices to a compute unit
+    # (slots + 1 / 3 / 2: workgroups of 64 / 128 / 512 threads); hulls beyond a form's slots are handed back
+    try:
+        for form in (97, 99, 98, 129, 131, 130, 161, 163, 162, 225, 227, 226, 481, 482):
+            os.environ["PCFIT_QHULL_FORM"] = str(form)
+            again = torch.full((S,), -7, dtype=torch.int64, device=dev)
+            F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(hn), None, S, total, p(scratch),
+                                                        total * 48, p(again), p(hx), p(hy), p(hi), -1, stream))
+            torch.cuda.synchronize()
+            again = again.cpu().numpy()
+            both = (again != -3) & (got != -3)
+            assert both.sum() > 500 and np.array_equal(again[both], got[both]), (form, int(both.sum()))
+    finally:
+        os.environ.pop("PCFIT_QHULL_FORM", None)
     F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
     F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(dnh), None, S, total, p(scratch),
                                                 total * 48, p(start), None, None, None, -1, stream))
