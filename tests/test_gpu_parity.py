@@ -605,6 +605,64 @@ def test_two_runs_are_bitwise_identical():
         assert np.array_equal(a[key], b[key], equal_nan=True), key
 
 
+@pytest.mark.parametrize("n_slices", [2600, 5000])
+def test_device_replay_on_batches_of_many_slices_equals_the_host_replay(n_slices):
+    """With more than five slices to a compute unit the replay runs in workgroups of 128 threads, with more than a
+    dozen in one wave a slice (the launcher picks by the batch): both against the host replay, slice by slice, on
+    the sorted distinct points and on the slices as they come (the route of a resident scan)."""
+    from oracle import qhull2d as Q
+    gen = np.random.default_rng(n_slices)
+    kinds = [k for k in Q.KINDS]
+    sets = []
+    for s_ in range(n_slices):
+        n = int(gen.choice([40, 150, 600, 2500]))
+        if s_ % 5 == 0:
+            th = gen.uniform(0, 2 * np.pi, n)
+            rad = 10 + gen.normal(0, 0.005, n)
+            xy = np.unique(np.round(np.stack([3 + rad * np.cos(th), -2 + rad * np.sin(th)], 1), 3), axis=0)
+        else:
+            xy = Q.make_case(kinds[int(gen.integers(len(kinds)))], n, int(gen.integers(1 << 30)))
+        sets.append(xy[gen.permutation(len(xy))])
+    def joined(sets):
+        off = np.concatenate([[0], np.cumsum([len(v) for v in sets])]).astype(np.int64)
+        return (np.ascontiguousarray(np.concatenate([v[:, 0] for v in sets])),
+                np.ascontiguousarray(np.concatenate([v[:, 1] for v in sets])), off)
+    # (hulls of up to 100 vertices only: the forms of 96 and 128 facet slots are the ones that come in narrow workgroups)
+    x, y, off = joined(sets)
+    small = F.unique_hull_batch(x, y, off)["n_hull"] <= 100
+    sets = [v for v, keep in zip(sets, small) if keep]
+    n_slices = len(sets)
+    assert n_slices > 2000
+    x, y, off = joined(sets)
+    why = np.zeros(16, np.int64)
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    h = F.unique_hull_batch(x, y, off, hull_start="qhull")
+    F.check(F.lib().pcfit_debug_qhull_reasons(F._p(why), 1))
+    host = F.qhull_order_batch(h["ux"], h["uy"], off, n_unique=h["n_unique"])
+    checked = 0
+    for s_ in range(n_slices):
+        nh = int(h["n_hull"][s_])
+        if nh < 3 or host["start"][s_] < 0:
+            continue
+        assert np.array_equal(h["hull_idx"][off[s_]:off[s_] + nh], host["walk"][off[s_]:off[s_] + host["n_walk"][s_]]), s_
+        checked += 1
+    assert checked > 0.8 * n_slices
+    assert int(h["n_hull"].max()) + 24 <= 128, int(h["n_hull"].max())      # (or the forms of 256 threads would have run)
+    assert int(why[:14].sum()) < 0.25 * n_slices, why.tolist()          # (the kernel answered most of them itself)
+    # the slices as they come: hull candidates of the hybrid chain in Qhull's order, with and without the list of
+    # distinct points (the second is the replay over unsorted slices with copies)
+    a = F.hybrid_batch(x, y, off, max_trials=20, want_profile=False, want_unique=True, order="qhull")
+    b = F.hybrid_batch(x, y, off, max_trials=20, want_profile=False, want_unique=False, order="qhull")
+    for k in ("status", "cand_offsets", "cand_x", "cand_y", "mask"):
+        assert np.array_equal(a[k], b[k]), k
+    for s_ in range(0, n_slices, 7):
+        nh = int(h["n_hull"][s_])
+        c0, c1 = a["cand_offsets"][s_], a["cand_offsets"][s_ + 1]
+        if a["status"][s_] == 0 and nh >= 3 and c1 - c0 == nh:
+            idx = h["hull_idx"][off[s_]:off[s_] + nh]
+            assert np.array_equal(a["cand_x"][c0:c1], h["ux"][off[s_] + idx]), s_
+
+
 def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
     """The analyzer as it comes (Config.hull_order = "qhull"): its candidates are the reference's
     `xy[hull.vertices]` in the reference's order, so every slice - the three whose hull holds outliers included -
