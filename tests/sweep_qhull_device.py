@@ -20,7 +20,14 @@ def main(rounds=20, seed=0):
     bad = open_ = slices = points = handed = quant = 0
     why_all = np.zeros(16, np.int64)
     t0 = time.time()
+    # SWEEP_FORMS=1: every round in another form of the kernel (facet slots and threads; PCFIT_QHULL_FORM is read at
+    # every call), the narrow ones that the launcher keeps for batches of thousands of slices among them; hulls
+    # beyond a form's slots are handed back
+    forms = np.random.default_rng(seed + 1)
     for r in range(rounds):
+        if os.environ.get("SWEEP_FORMS"):
+            os.environ["PCFIT_QHULL_FORM"] = str(forms.choice([96, 97, 98, 99, 128, 129, 130, 131, 160, 161, 162, 163, 224,
+                                                               225, 226, 227, 480, 481, 482]))
         xs, ys, off = [], [], [0]
         for k in range(int(gen.integers(50, 600))):
             n = int(gen.choice([3, 4, 6, 10, 30, 200, 1500, 8192, 9000, 30000, 70000]))
