@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -540,6 +542,41 @@ PCFIT_API int pcfit_ovality_long_dev(const double *x, const double *y, const int
     return PCFIT_OK;
 }
 
+// The points of a slice on the host, sorted by (x, y) with copies left out, in place; returns how many are left.
+// A counting sort on a bucket number that never decreases with x (two buckets a point over the range of x), then
+// a comparison sort inside every bucket - a point or two as a rule: a quarter of the time of one comparison sort.
+static int64_t sort_distinct_points(double *x, double *y, int64_t m)
+{
+    typedef std::pair<double, double> P;
+    std::vector<P> pts((size_t)m);
+    double lo = 0.0, hi = 0.0;
+    bool finite = m > 0;
+    for (int64_t i = 0; i < m; i++) {
+        pts[(size_t)i] = {x[i], y[i]};
+        finite = finite && std::isfinite(x[i]);
+        lo = i == 0 || x[i] < lo ? x[i] : lo;
+        hi = i == 0 || x[i] > hi ? x[i] : hi;
+    }
+    const double scale = finite && hi > lo ? (double)(2 * m) / (hi - lo) : 0.0;
+    if (m >= 256 && m < (1ll << 30) && scale > 0.0 && std::isfinite(scale)) {
+        const int64_t B = 2 * m + 1;
+        auto bucket = [&](double v) { const int64_t b = (int64_t)((v - lo) * scale); return b < 0 ? 0 : b >= B ? B - 1 : b; };
+        std::vector<int32_t> first((size_t)B + 1, 0);
+        for (int64_t i = 0; i < m; i++) first[(size_t)bucket(pts[(size_t)i].first) + 1]++;
+        for (int64_t b = 0; b < B; b++) first[(size_t)b + 1] += first[(size_t)b];
+        std::vector<P> out((size_t)m);
+        std::vector<int32_t> at(first.begin(), first.end() - 1);
+        for (int64_t i = 0; i < m; i++) out[(size_t)at[(size_t)bucket(pts[(size_t)i].first)]++] = pts[(size_t)i];
+        for (int64_t b = 0; b < B; b++)
+            if (first[(size_t)b + 1] - first[(size_t)b] > 1) std::sort(out.begin() + first[(size_t)b], out.begin() + first[(size_t)b + 1]);
+        pts.swap(out);
+    } else
+        std::sort(pts.begin(), pts.end());
+    pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+    for (size_t i = 0; i < pts.size(); i++) { x[i] = pts[i].first; y[i] = pts[i].second; }
+    return (int64_t)pts.size();
+}
+
 // hull_start entries of PCFIT_HULL_START_QHULL: the walks of those slices are turned to the vertex that Qhull's
 // construction leaves first.  The construction is replayed on the device (qhull_dev.hip) from the points in
 // (px, py): the slices' sorted distinct points (counts in n_pts / d_n_pts), or the slices as they are
@@ -584,28 +621,50 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
         }
     if (!which.empty()) {
         PCFIT_TRY(dxy.download(start_xy.data(), (size_t)S * 16, st));
-        std::vector<double> hx((size_t)coff.back()), hy((size_t)coff.back());
+        // (through the thread's pinned scratch when it holds them: copies into pageable memory run at half the rate
+        // and each of them blocks)
+        const size_t bytes = (size_t)coff.back() * 8;
+        double *pin = bytes <= ((size_t)64 << 20) ? static_cast<double *>(pinned_scratch(2 * bytes)) : nullptr;
+        std::vector<double> spare(pin ? 0 : 2 * (size_t)coff.back());
+        double *const hx = pin ? pin : spare.data(), *const hy = hx + coff.back();
         for (size_t k = 0; k < which.size(); k++) {
             const int64_t s = which[k];
-            PCFIT_HIP(hipMemcpyAsync(hx.data() + coff[k], px + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
-            PCFIT_HIP(hipMemcpyAsync(hy.data() + coff[k], py + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
+            PCFIT_HIP(hipMemcpyAsync(hx + coff[k], px + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
+            PCFIT_HIP(hipMemcpyAsync(hy + coff[k], py + offsets[s], (size_t)n_pts[s] * 8, hipMemcpyDeviceToHost, st));
         }
         PCFIT_HIP(hipStreamSynchronize(st));
+        // (the slices go to host threads, as they do in the replay)
         std::vector<int64_t> counts(which.size());
-        for (size_t k = 0; k < which.size(); k++) {
+        auto sort_slice = [&](size_t k) {
             int64_t m = coff[k + 1] - coff[k];
             if (raw) {
-                std::vector<std::pair<double, double>> pts((size_t)m);
-                for (int64_t i = 0; i < m; i++) pts[(size_t)i] = {hx[coff[k] + i], hy[coff[k] + i]};
-                std::sort(pts.begin(), pts.end());
-                pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
-                m = (int64_t)pts.size();
-                for (int64_t i = 0; i < m; i++) { hx[coff[k] + i] = pts[(size_t)i].first; hy[coff[k] + i] = pts[(size_t)i].second; }
+                m = sort_distinct_points(hx + coff[k], hy + coff[k], m);
             }
             counts[k] = m;
+        };
+        {
+            const size_t n = which.size();
+            const size_t T = raw ? std::min<size_t>(n, std::min(16u, std::max(1u, std::thread::hardware_concurrency()))) : 1;
+            std::atomic<size_t> next{0};
+            std::atomic<int> failed{0};
+            auto work = [&]() {
+                try {
+                    for (size_t k; (k = next.fetch_add(1)) < n;) sort_slice(k);
+                } catch (...) {
+                    failed.store(1);
+                }
+            };
+            std::vector<std::thread> pool;
+            try {
+                for (size_t t = 1; t < T; t++) pool.emplace_back(work);
+            } catch (...) {                   // no more threads: the ones there are share the slices
+            }
+            work();
+            for (auto &th : pool) th.join();
+            if (failed.load()) throw std::bad_alloc();
         }
         std::vector<int64_t> cstart(which.size(), -1);
-        PCFIT_TRY(qhull_start_host(hx.data(), hy.data(), coff.data(), counts.data(), (int64_t)which.size(), 0, nullptr,
+        PCFIT_TRY(qhull_start_host(hx, hy, coff.data(), counts.data(), (int64_t)which.size(), 0, nullptr,
                                    cstart.data(), nullptr, nullptr, nullptr));
         for (size_t k = 0; k < which.size(); k++) {
             const int64_t s = which[k];
