@@ -55,9 +55,9 @@ struct QPhase {
 namespace {
 
 constexpr int QF_MAX = 480;      // live facets of a slice (slot 0 is the list's tail): the kernel's roomiest form
-constexpr int QP = 5;            // pieces an outside set may lie in
+constexpr int QP = 4;            // pieces an outside set may lie in
 constexpr int QV = 6;            // visible facets of one insertion
-constexpr int QU = 32;           // points of one insertion that go through the horizon search
+constexpr int QU = 16;           // points of one insertion that go through the horizon search
 constexpr int64_t QHULL_DEFER = QHULL_START_DEFER;
 constexpr unsigned IDX_MASK = 0x7fffffffu;      // a piece's start; the top bit names the buffer it lies in
 
@@ -109,9 +109,8 @@ struct Shared {
     // points below both new facets by less than a roundoff unit: Qhull searches the horizon for them
     int unc_slot[QU], unc_from[QU], n_unc, gap_used[QV * QP];
     double unc_d[QU], unc_x[QU], unc_y[QU];
-    unsigned short visit[QF], visit_id;
     short copl[64];
-    unsigned wave_seen[QT / 64][(QF + 31) / 32];     // wave_horizon's visit marks and stack, one set per wave
+    unsigned wave_seen[QT / 64][(QF + 31) / 32];     // the visit marks and the stack of a horizon walk, one set per wave
     short wave_copl[QT / 64][16];
     double red_d[QT / 64];
     int red_i[QT / 64];
@@ -419,10 +418,9 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     // entries, the second 2 m (what the upper half is for: see the first partition).
     double2 *const bufs0 = buf_a + off, *const bufs1 = buf_b + 2 * off;
 
-    // (the free list and the visit marks: idle until the simplex is made, several barriers from here)
+    // (the free list: idle until the simplex is made, several barriers from here)
     for (int k = tid; k < QF; k += QT) {
         S.free_slot[k] = (short)(QF - 1 - k);       // slots QF-1 .. 1 (0 is the tail)
-        S.visit[k] = 0;
     }
     // qh_maxmin, qh_detroundoff, qh_maxsimplex.  The four coordinate extremes - least x, greatest x, least y, greatest
     // y, each the lexicographically first point among equals - by their coordinates: they are vertices of the hull,
@@ -558,7 +556,6 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
     if (tid == lt) {
         // qh_createsimplex, qh_initialhull
         S.n_free = QF - 1;
-        S.visit_id = 0;
         S.head = S.nextf = 0;
         S.prev[0] = -1;
         S.next[0] = 0;
@@ -950,13 +947,14 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 const double px = S.unc_x[k], py = S.unc_y[k];
                 double bestdist = S.unc_d[k], minsearch = bestdist - searchdist;
                 int bestf = S.unc_from[k], facet = bestf, nextfacet = 0, size = 0;
-                const unsigned short id = ++S.visit_id;
-                S.visit[bestf] = id;
+                unsigned *seen = S.wave_seen[lt >> 6];       // (this wave's own marks: no wave walks by now)
+                for (int w = 0; w < (QF + 31) / 32; w++) seen[w] = 0u;
+                seen[bestf >> 5] |= 1u << (bestf & 31);
                 while (true) {
                     for (int j = 0; j < 2; j++) {
                         const int nb = j ? S.nb1[facet] : S.nb0[facet];
-                        if (S.visit[nb] == id || S.visible[nb]) continue;
-                        S.visit[nb] = id;
+                        if (((seen[nb >> 5] >> (nb & 31)) & 1u) || S.visible[nb]) continue;
+                        seen[nb >> 5] |= 1u << (nb & 31);
                         const double d = plane_dist(S, nb, px, py);
                         if (d > bestdist) {
                             minsearch = d - searchdist;
@@ -1018,10 +1016,10 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
         bool answered = false;
         if (S.state == 1) {
             // scipy's walk from the head of the list; facets in one line are one facet in Qhull's result (it merged
-            // them), standing in the list where the newest part stands.  (The free list, the visit marks and the
+            // them), standing in the list where the newest part stands.  (The free list, the sets' sizes and the
             // visibility flags are idle by now and hold the walk, the places in the list and the joints.)
             short *walk = S.free_slot;
-            unsigned short *place = S.visit;
+            int *place = S.total;
             unsigned char *joined = S.visible;
             int nw = 0, k = 0;
             for (int f = S.head; nw < QF;) {
@@ -1029,7 +1027,7 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                 f = S.top[f] ? S.nb0[f] : S.nb1[f];
                 if (f == S.head) break;
             }
-            for (int g = S.head; g != 0 && k < QF; g = S.next[g]) place[g] = (unsigned short)k++;
+            for (int g = S.head; g != 0 && k < QF; g = S.next[g]) place[g] = k++;
             const double radius = 2 * S.thr[0];
             int n_joined = 0;
             auto centrum_dist = [&](int of, int to) {          // a facet's centrum, brought onto its own line, from another's line
@@ -1137,10 +1135,11 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
     int dev = 0, cus = 256;
     PCFIT_HIP(hipGetDevice(&dev));
     PCFIT_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const int slots = need <= 96 ? 96 : need <= 128 ? 128 : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;
+    int slots = need <= 96 ? 96 : need <= 112 ? 112 : need <= 128 ? 128 : need <= 144 ? 144 : need <= 160 ? 160 : need <= 224 ? 224 : QF_MAX;
     const bool wide = n_slices <= 256 && total / n_slices >= 32768;
     const int64_t per_cu = (n_slices + cus - 1) / std::max(cus, 1);
-    const int threads = wide ? 2 : (slots > 128 || per_cu <= 5) ? 0 : per_cu <= 12 ? 3 : 1;
+    const int threads = wide ? 2 : (slots > 160 || per_cu <= 5) ? 0 : per_cu <= 12 ? 3 : 1;
+    if ((threads == 0 || threads == 2) && (slots == 112 || slots == 144)) slots += 16;     // (narrow forms only)
     const int form = forced ? forced : slots + threads;
     const dim3 grid((unsigned)n_slices);
     double2 *const pairs = reinterpret_cast<double2 *>(scratch);
@@ -1155,16 +1154,20 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
     case 97: PCFIT_QHULL_LAUNCH(96, 10, 64); break;
     case 98: PCFIT_QHULL_LAUNCH(96, 2, 512); break;
     case 99: PCFIT_QHULL_LAUNCH(96, 8, 128); break;
+    case 113: PCFIT_QHULL_LAUNCH(112, 9, 64); break;
+    case 115: PCFIT_QHULL_LAUNCH(112, 8, 128); break;
     case 128: PCFIT_QHULL_LAUNCH(128, 5, 256); break;
     case 129: PCFIT_QHULL_LAUNCH(128, 8, 64); break;
     case 130: PCFIT_QHULL_LAUNCH(128, 2, 512); break;
-    case 131: PCFIT_QHULL_LAUNCH(128, 7, 128); break;
+    case 131: PCFIT_QHULL_LAUNCH(128, 8, 128); break;
+    case 145: PCFIT_QHULL_LAUNCH(144, 8, 64); break;
+    case 147: PCFIT_QHULL_LAUNCH(144, 8, 128); break;
     case 160: PCFIT_QHULL_LAUNCH(160, 5, 256); break;
-    case 161: PCFIT_QHULL_LAUNCH(160, 8, 64); break;
+    case 161: PCFIT_QHULL_LAUNCH(160, 7, 64); break;
     case 162: PCFIT_QHULL_LAUNCH(160, 2, 512); break;
-    case 163: PCFIT_QHULL_LAUNCH(160, 6, 128); break;
+    case 163: PCFIT_QHULL_LAUNCH(160, 7, 128); break;
     case 224: PCFIT_QHULL_LAUNCH(224, 5, 256); break;
-    case 225: PCFIT_QHULL_LAUNCH(224, 6, 64); break;
+    case 225: PCFIT_QHULL_LAUNCH(224, 5, 64); break;
     case 226: PCFIT_QHULL_LAUNCH(224, 2, 512); break;
     case 227: PCFIT_QHULL_LAUNCH(224, 4, 128); break;
     case QF_MAX + 1: PCFIT_QHULL_LAUNCH(QF_MAX, 3, 64); break;

@@ -26,7 +26,7 @@ def main(rounds=20, seed=0):
     forms = np.random.default_rng(seed + 1)
     for r in range(rounds):
         if os.environ.get("SWEEP_FORMS"):
-            os.environ["PCFIT_QHULL_FORM"] = str(forms.choice([96, 97, 98, 99, 128, 129, 130, 131, 160, 161, 162, 163, 224,
+            os.environ["PCFIT_QHULL_FORM"] = str(forms.choice([96, 97, 98, 99, 113, 115, 128, 129, 130, 131, 145, 147, 160, 161, 162, 163, 224,
                                                                225, 226, 227, 480, 481, 482]))
         xs, ys, off = [], [], [0]
         for k in range(int(gen.integers(50, 600))):

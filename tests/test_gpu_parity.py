@@ -230,7 +230,7 @@ def test_device_replay_of_qhulls_order_against_scipys_lists_and_the_host_replay(
     # ... the narrow and the wide ones too, which the library picks by the number of slices to a compute unit
     # (slots + 1 / 3 / 2: workgroups of 64 / 128 / 512 threads); hulls beyond a form's slots are handed back
     try:
-        for form in (97, 99, 98, 129, 131, 130, 161, 163, 162, 225, 227, 226, 481, 482):
+        for form in (97, 99, 98, 113, 115, 129, 131, 130, 145, 147, 161, 163, 162, 225, 227, 226, 481, 482):
             os.environ["PCFIT_QHULL_FORM"] = str(form)
             again = torch.full((S,), -7, dtype=torch.int64, device=dev)
             F.check(F.lib().pcfit_qhull_start_batch_dev(p(dx), p(dy), p(doff), p(dnu), p(hn), None, S, total, p(scratch),
