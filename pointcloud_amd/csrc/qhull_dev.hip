@@ -1121,12 +1121,13 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
     const int64_t need = max_hull < 0 ? QF_MAX : max_hull + std::max(margin, 2);
     // A slice's construction is a chain of short phases (0.7 ms of dependent latency for a slice of 50 000 points
     // however many threads work on it), so what fills the chip is the number of slices in flight, and the LDS of the
-    // facet slots is what limits it: 5 slices to a compute unit in workgroups of 256 threads (registers), 8 of 128
-    // threads and 10 of 64 with 96 slots, 7 with 128 slots, 6 with 160 whatever the threads.  Measured on 96 slots,
-    // slices of 5000 to 100 000 points: up to 5 slices a compute unit 256 threads win (1000 x 100 000: 1.94 ms
-    // against 2.09 with 128), up to a dozen 128 threads (2000 x 50 000: 1.77 against 2.45 with 256, 1.85 with 64),
-    // beyond that one wave a slice (10 000 x 8192: 2.03 against 2.39 and 3.70; 20 000 x 5000: 2.67, 3.49, 5.57).
-    // With 160 slots and more the narrow forms gain nothing (six slices to a compute unit against five).
+    // facet slots (131 bytes each) is what limits it: 11 / 10 / 8 / 8 / 7 / 5 / 2 slices to a compute unit with 96 /
+    // 112 / 128 / 144 / 160 / 224 / 480 slots, and no more than 5 in workgroups of 256 threads or 8 of 128 threads
+    // (registers).  Measured on 96 slots, slices of 5000 to 100 000 points: up to 5 slices a compute unit 256
+    // threads win (1000 x 100 000: 1.94 ms against 2.09 with 128), up to a dozen 128 threads (2000 x 50 000: 1.77
+    // against 2.45 with 256, 1.85 with 64), beyond that one wave a slice (10 000 x 8192: 2.03 against 2.39 and
+    // 3.70; 20 000 x 5000: 2.67, 3.49, 5.57).  With more than 160 slots the narrow forms hold no more slices
+    // than the wide ones.
     // Few long slices (a scan cut into some dozen windows): a slice's passes are chains of turns of one point a
     // thread, each a trip to memory long, and with no more slices than compute units there is nothing to fill the
     // chip with but threads - workgroups of 512 then.  Measured on 57 to 256 slices of 50 000 to 1 000 000 points:
