@@ -49,6 +49,7 @@ FLOP_SWEEP_FIRST = 36.0
 FLOP_SWEEP = 43.0
 FLOP_RESID = 23.0
 PEAK_FP64_VALU_TFLOPS = 78.6
+SETTLE = 64          # launches before the warmup steps: the clock of an idle GPU needs them
 RING = 8                      # record buffers in flight between the fit kernel and the all-gather
 PEAK_HBM_GBS = 8000.0
 
@@ -129,6 +130,17 @@ def cpu_baseline_c(x, y, off, bins, lo, hi, n_slices=600, threads=1):
     return off[n_slices] / dt, n_slices, dt
 
 
+def settle(fn, ms=40.0):
+    """Runs fn (GPU work, enqueued) again and again for `ms` of wall clock, at least twice, and waits for it: the clock
+    of an idle GPU takes some 20 ms of load to come up, and a timing taken before that is the timing of the ramp."""
+    t0 = time.perf_counter()
+    k = 0
+    while k < 2 or time.perf_counter() - t0 < ms * 1e-3:
+        fn()
+        torch.cuda.synchronize()
+        k += 1
+
+
 def extra_configs(L, dev, stream):
     """Timings of the other configurations, outside the timed region (events on the kernels' stream):
     seeded RANSAC on 10 000 slices x 8192 points with 30 % outliers and 1024 hypotheses per slice; a 100 M-point
@@ -138,7 +150,7 @@ def extra_configs(L, dev, stream):
     out = {}
 
     def timed(fn, reps):
-        fn()
+        settle(fn)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
@@ -210,8 +222,8 @@ def extra_configs(L, dev, stream):
     def scatter():
         F.check(L.pcfit_bin2_scatter_dev(n, S, F._p(geom), 0, n + n // 8, ptr(off), ptr(xo), ptr(yo), None, ptr(ws), wsb,
                                          stream))
-    ms_count = timed(count, 3)
-    ms_scatter = timed(scatter, 3)
+    ms_count = timed(count, 10)
+    ms_scatter = timed(scatter, 10)
     ms = ms_count + ms_scatter
     out["binning_100M_points_2000_windows_random_z_order"] = {
         "ms": ms, "ms_level1_and_counts": ms_count, "ms_level2_scatter": ms_scatter,
@@ -234,19 +246,19 @@ def extra_configs(L, dev, stream):
     t_up = time.perf_counter()
     with DeviceScan(host) as scan:
         t_up = time.perf_counter() - t_up
-        res = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="canonical")
+        settle(lambda: F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="canonical"))
         t_an = time.perf_counter()
-        for _ in range(3):
+        for _ in range(5):
             res = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="canonical")
-        t_an = (time.perf_counter() - t_an) / 3
+        t_an = (time.perf_counter() - t_an) / 5
         # the same with every hull listed as scipy's ConvexHull lists it (the analyzer's default: a kernel replays
         # Qhull's construction per window, the few windows it hands back are replayed on host cores): the
         # reference's candidates element for element
-        res_q = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="qhull")
+        settle(lambda: F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="qhull"))
         t_q = time.perf_counter()
-        for _ in range(3):
+        for _ in range(5):
             res_q = F.scan_hybrid_batch(scan, zc - 1.0, zc + 1.0, order="qhull")
-        t_q = (time.perf_counter() - t_q) / 3
+        t_q = (time.perf_counter() - t_q) / 5
     t_up2 = time.perf_counter()
     with DeviceScan(host):
         t_up2 = time.perf_counter() - t_up2
@@ -271,23 +283,23 @@ def extra_configs(L, dev, stream):
     iters = torch.empty(S, 4, dtype=torch.int32, device=dev)
     st = torch.empty(S, dtype=torch.int32, device=dev)
     ms_fit = timed(lambda: F.check(L.pcfit_fit_batch_dev(ptr(xo), ptr(yo), ptr(off), S, longest, 1.0, 100, 1e-2, 1e-10,
-                                                         1e-12, ptr(kasa), ptr(fit), ptr(iters), ptr(st), stream)), 3)
+                                                         1e-12, ptr(kasa), ptr(fit), ptr(iters), ptr(st), stream)), 10)
     sweeps = float((iters[:, 2] + iters[:, 3]).double().mean().item())
     sel = torch.empty(S, 720, dtype=torch.int64, device=dev)
     ms_sel = timed(lambda: F.check(L.pcfit_angle_max_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), 720, ptr(sel),
-                                                               stream)), 3)
+                                                               stream)), 10)
     H = 256
     edges = torch.linspace(-0.5, 0.5, H + 1, dtype=torch.float64, device=dev)
     hist = torch.empty(S, H, dtype=torch.int64, device=dev)
     rmm = torch.empty(S, 2, dtype=torch.float64, device=dev)
     amm = torch.empty(S, 2, dtype=torch.int64, device=dev)
     ms_hist = timed(lambda: F.check(L.pcfit_residuals_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), None, None, None,
-                                                                H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream)), 3)
+                                                                H, ptr(edges), ptr(hist), ptr(rmm), ptr(amm), stream)), 10)
     # both from one read of every window (pcfit_boundary_residuals_batch_dev), and that they are the same numbers
     sel1, hist1, amm1 = torch.empty_like(sel), torch.empty_like(hist), torch.empty_like(amm)
     ms_both = timed(lambda: F.check(L.pcfit_boundary_residuals_batch_dev(ptr(xo), ptr(yo), ptr(off), S, ptr(fit), 720,
                                                                          ptr(sel1), H, ptr(edges), ptr(hist1), ptr(rmm),
-                                                                         ptr(amm1), stream)), 3)
+                                                                         ptr(amm1), stream)), 10)
     same = bool(torch.equal(sel, sel1) and torch.equal(hist, hist1) and torch.equal(amm, amm1))
     gbs = lambda ms_, passes: 16.0 * tot * passes / (ms_ * 1e-3) / 1e9
     out["boundary_and_histograms_100M_points_2000_windows"] = {
@@ -319,8 +331,8 @@ def launch_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--slices", type=int, default=10_000)
     ap.add_argument("--points", type=int, default=8192)
     ap.add_argument("--bins", type=int, default=256)
@@ -425,6 +437,19 @@ def main():
                 pending[b].wait()
                 pending[b] = None
 
+    # An idle GPU takes some 20 ms of load to bring its clock up (launch durations from idle on this part: 0.55 ms
+    # at the 10th launch, 0.50 at the 30th, 0.48 from the 40th on), so the kernel runs SETTLE times before the warmup
+    # steps: what is timed is the rate of a GPU at work, and the line names what the first launches took.
+    settle_ev = []
+    for i in range(SETTLE):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        F.check(L.pcfit_fit_residuals_batch_dev(ptr(x), ptr(y), ptr(off), S, n, 1.0, 100, 1e-2, 1e-10, 1e-12,
+                                                ptr(kasa), ptr(fit[0]), ptr(iters), ptr(status), H, ptr(edges),
+                                                ptr(hist), ptr(rmm), ptr(amm), stream))
+        e1.record()
+        settle_ev.append((e0, e1))
     for i in range(a.warmup):
         step(i, False)
     drain()
@@ -452,8 +477,8 @@ def main():
     it = iters.cpu().numpy().astype(np.float64)
 
     # the subsystems on their own, after the timed region: algebraic fit, fit without residuals, residuals
-    def timed(fn, reps=5):
-        fn()
+    def timed(fn, reps=20):
+        settle(fn)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -487,7 +512,11 @@ def main():
                          "hbm_frac": S * n * 16 / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS})
 
     ms_step = dt / a.steps * 1e3
-    k_ms = float(np.mean([s.elapsed_time(e) for s, e in ev_k]))
+    settle_ms = [s.elapsed_time(e) for s, e in settle_ev]
+    per_launch = [s.elapsed_time(e) for s, e in ev_k]
+    k_ms = float(np.mean(per_launch))
+    if os.environ.get("PCFIT_BENCH_DEBUG") == "1" and rank == 0:
+        print("[bench] launch durations (ms), every 10th: " + " ".join(f"{v:.3f}" for v in per_launch[::10]), file=sys.stderr)
     sweeps = it[:, 2] + it[:, 3]
     flop_launch = float(n * (FLOP_SWEEP_FIRST * it[:, 2].sum() + FLOP_SWEEP * it[:, 3].sum() + (FLOP_KASA + FLOP_RESID) * S))
     alg_bytes = float(S * n * 16)
@@ -509,6 +538,10 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": ms_step,
+            # launches before the warmup steps (untimed): the clock of an idle GPU comes up over the first ~40 of them
+            "clock_settling": {"launches_before_warmup": SETTLE,
+                               "ms_per_launch_2nd_to_21st_from_idle": float(np.mean(settle_ms[1:21])) if len(settle_ms) > 21 else None,
+                               "ms_per_launch_last_10_of_them": float(np.mean(settle_ms[-10:])) if settle_ms else None},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -8,7 +8,7 @@ cd $R
 timeout -k 10 300 python3 bench.py > gpurun_out/$TAG/bench.json 2> gpurun_out/$TAG/bench.err
 tail -c 2500 gpurun_out/$TAG/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o t --output-format csv -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-side > $R/gpurun_out/$TAG/trace.log 2>&1
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$TAG/trace -o t --output-format csv -- python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-side > $R/gpurun_out/$TAG/trace.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/$TAG/pmc_fetch -o f --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-side > $R/gpurun_out/$TAG/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/$TAG/pmc_write -o w --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --no-side > $R/gpurun_out/$TAG/pmc_write.log 2>&1
 A="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS"

@@ -10,6 +10,22 @@ if stats:
         csv.writer(f).writerows(rows)
     for r in rows[:6]:
         print(r)
+# the timed launches alone: bench.py runs the kernel 64 times before its warmup steps (the clock of an idle GPU comes
+# up over the first ~40), so the mean over all launches in the stats file lies a little above the mean of the last 200
+trace = glob.glob(os.path.join(src, "trace", "**", "*kernel_trace.csv"), recursive=True)
+if trace:
+    rows = [r for r in csv.DictReader(open(trace[0])) if "fit_residual_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    if len(dur) >= 200:
+        with open(os.path.join(root, "profiles", f"{name}_kernel_trace_fused_launches.txt"), "w") as f:
+            f.write(f"# fit_residual_kernel launches of `bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-side` "
+                    f"under rocprofv3 --kernel-trace, in order: {len(dur)} launches (64 to settle the clock, 20 warmup, 200 timed)\n")
+            f.write(f"mean of all launches: {sum(dur) / len(dur):.1f} us\n")
+            f.write(f"mean of launches 2 to 21 (from idle): {sum(dur[1:21]) / 20:.1f} us\n")
+            f.write(f"mean of the last 200 (the timed steps): {sum(dur[-200:]) / 200:.1f} us\n")
+            f.write("every 10th launch, us: " + " ".join(f"{v:.0f}" for v in dur[::10]) + "\n")
+        print(open(os.path.join(root, "profiles", f"{name}_kernel_trace_fused_launches.txt")).read())
 out = [["counter", "kernel", "dispatches", "mean_KiB", "min_KiB", "max_KiB"]]
 per = {}
 for cname, d in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
@@ -30,7 +46,7 @@ from bench import kernel_sources_sha1
 traffic = {"source": [f"profiles/{name}_pmc_hbm.csv", f"profiles/{name}_bench_pmc_sq.csv"],
            "kernel_sources_sha1": kernel_sources_sha1(),
            "note": "HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE (KiB counters, separate --pmc passes; gfx950 "
-                   "FETCH_SIZE reports half of a streaming read), bench.py --steps 3, 10000 slices x 8192 points",
+                   "FETCH_SIZE reports half of a streaming read), bench.py --steps 3 --warmup 1 (+ 64 launches before them), 10000 slices x 8192 points",
            "algorithmic_bytes_per_launch": 10000 * 8192 * 16}
 for k, v in per.items():
     if "fit_residual_kernel" in k and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
