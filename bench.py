@@ -441,6 +441,8 @@ def main():
     # at the 10th launch, 0.50 at the 30th, 0.48 from the 40th on), so the kernel runs SETTLE times before the warmup
     # steps: what is timed is the rate of a GPU at work, and the line names what the first launches took.
     settle_ev = []
+    if use_dist:
+        dist.barrier()          # (the ranks get here seconds apart: they settle, warm up and reach the timed region together)
     for i in range(SETTLE):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
