@@ -75,7 +75,7 @@ struct Far {
     {
         if (!o.has) return;
         if (!has || o.d > d) *this = o;
-        else if (o.d == d && (o.x != x || o.y != y)) tie = 1;
+        else if (o.d == d && (o.tie || o.x != x || o.y != y)) tie = 1;      // (o may hold a copy of this point and know of a tie)
     }
     // The same where the points arrive in the order of the sorted distinct array, whatever order they are read in
     // (Qhull's first partition): of two points at the greatest distance the lexicographically first is the one
