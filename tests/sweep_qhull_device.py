@@ -42,6 +42,8 @@ def main(rounds=20, seed=0):
                 xy = make_case(KINDS[int(gen.integers(len(KINDS)))], n, int(gen.integers(1 << 30)))
             if gen.random() < 0.2:                       # duplicates and another order: the library sorts and dedups
                 xy = np.concatenate([xy, xy[gen.integers(0, len(xy), len(xy) // 3 + 1)]])
+            elif gen.random() < 0.15:                    # every point several times over: copies of a set's farthest
+                xy = np.repeat(xy, int(gen.integers(2, 6)), axis=0)      # point meet in different waves
             xy = xy[gen.permutation(len(xy))]
             xs.append(xy[:, 0]), ys.append(xy[:, 1]), off.append(off[-1] + len(xy))
         x, y, off = np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64)

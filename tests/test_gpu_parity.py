@@ -663,6 +663,30 @@ def test_device_replay_on_batches_of_many_slices_equals_the_host_replay(n_slices
             assert np.array_equal(a["cand_x"][c0:c1], h["ux"][off[s_] + idx]), s_
 
 
+def test_replay_over_slices_with_many_copies_of_every_point():
+    """Slices as they come, every point several times over, coordinates rounded so that sets have ties for their
+    farthest point: copies of one point then meet in different waves' partial results, and a tie that only one of
+    them knows of must survive the join (the slice is handed back, not answered).  Against the route over the sorted
+    distinct points, which has no copies."""
+    gen = np.random.default_rng(77)
+    sets = []
+    for s_ in range(int(os.environ.get("COPIES_SLICES", "1200"))):
+        n = int(gen.choice([300, 1000, 3000]))
+        th = gen.uniform(0, 2 * np.pi, n)
+        rad = 10 + gen.normal(0, 0.05, n)
+        xy = np.unique(np.round(np.stack([3 + rad * np.cos(th), -2 + rad * np.sin(th)], 1) * 8.0) / 8.0, axis=0)
+        xy = np.repeat(xy, int(gen.integers(2, 6)), axis=0)
+        sets.append(xy[gen.permutation(len(xy))])
+    off = np.concatenate([[0], np.cumsum([len(v) for v in sets])]).astype(np.int64)
+    x = np.ascontiguousarray(np.concatenate([v[:, 0] for v in sets]))
+    y = np.ascontiguousarray(np.concatenate([v[:, 1] for v in sets]))
+    srt = F.hybrid_batch(x, y, off, max_trials=20, want_profile=False, want_unique=True, order="qhull")
+    for rep in range(6):                 # (which wave sees which copy changes from run to run)
+        raw = F.hybrid_batch(x, y, off, max_trials=20, want_profile=False, want_unique=False, order="qhull")
+        for k in ("status", "cand_offsets", "cand_x", "cand_y", "mask"):
+            assert np.array_equal(raw[k], srt[k]), (rep, k)
+
+
 def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
     """The analyzer as it comes (Config.hull_order = "qhull"): its candidates are the reference's
     `xy[hull.vertices]` in the reference's order, so every slice - the three whose hull holds outliers included -
