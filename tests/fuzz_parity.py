@@ -78,6 +78,19 @@ def make_slice(g, n):
     return kind, np.ascontiguousarray(xy)
 
 
+def few_points_tol(xy, radius):
+    """What three or four points leave to rounding, against the circle's size: 1e-7 when they are almost in line (a
+    circle twenty times their spread: one coordinate moved by a unit in the last place moves it by 4e-9), and 1e-9
+    times a ten-thousandth of (spread / least distance between two of them)^2 when two of them nearly coincide - the
+    normal equations square that ratio (points 0.03 apart and 28 from the third: two kernels 1.1e-9 apart)."""
+    spread = float(np.ptp(xy[:, 0]) + np.ptp(xy[:, 1]))
+    if abs(radius) > 20.0 * spread:
+        return 1e-7
+    u = np.unique(xy, axis=0)
+    d = min(float(np.hypot(*(u[i] - u[j]))) for i in range(len(u)) for j in range(i))
+    return 1e-9 * max(1.0, 1e-4 * (spread / d) ** 2) if d > 0 else 1e-7
+
+
 def in_one_line(xy):
     """Fewer than three distinct points, or all of them exactly in one line (a handful of points on a coarse grid can
     be): no circle is determined, and what a fit returns is the rounding of a zero determinant - on both sides."""
@@ -142,11 +155,7 @@ def one_round(seed):
             if kinds[s] in ("ring", "dups", "tiny", "grid") and sizes[s] >= 3:
                 want = lm[s] if max_iter else kasa[s]
                 err = float(np.max(np.abs(fu["fit"][s] - want)) / np.abs(want).max())     # against the circle's size
-                # (three or four points of a ring can lie almost in line: a circle of radius 3000 through points 2
-                # apart moves by 4e-9 when one coordinate moves by one unit in the last place)
-                spread = float(np.ptp(x[off[s]:off[s + 1]]) + np.ptp(y[off[s]:off[s + 1]]))
-                flat = sizes[s] <= 4 and abs(want[2]) > 20.0 * spread
-                if not err <= (1e-7 if flat else 1e-9):
+                if not err <= (few_points_tol(sets[s], want[2]) if sizes[s] <= 4 else 1e-9):
                     note(seed, int(s), "fused fit", f"{tag} {err:.2e}")
     sel = F.angle_max_batch(x, y, off, init, bins=90)
     uh = F.unique_hull_batch(x, y, off)
@@ -165,9 +174,7 @@ def one_round(seed):
             # errors are measured against the circle's size: a centre coordinate may be arbitrarily close to zero
             elif st == 0 and kinds[s] not in ("line", "same") and not (n <= 16 and in_one_line(xy)):
                 err = float(np.max(np.abs(kasa[s] - k)) / np.abs(k).max())
-                # (three or four points almost in line - a circle twenty times their spread - as for the fused fit below)
-                flat = n <= 4 and abs(k[2]) > 20.0 * float(np.ptp(xy[:, 0]) + np.ptp(xy[:, 1]))
-                if not err <= (1e-6 if kinds[s] == "far" else 1e-7 if flat else 1e-9):
+                if not err <= (1e-6 if kinds[s] == "far" else few_points_tol(xy, k[2]) if n <= 4 else 1e-9):
                     note(seed, s, "kasa value", f"{tag} {err:.2e}")
         # LM from the same start
         if n >= 3 and kinds[s] not in ("line", "same") and not (n <= 16 and in_one_line(xy)):
