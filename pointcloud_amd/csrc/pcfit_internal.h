@@ -30,7 +30,7 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
                      int64_t *walk, int64_t *n_walk);
 int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, const double *uy,
                     const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
-                    hipStream_t st);
+                    hipStream_t st, const void *verts = nullptr, const int32_t *vcount = nullptr, int vstride = 0);
 // qhull_dev.hip: the same replay on the device, one workgroup per slice, of slices that are sorted and distinct
 // (n_unique points each) or as they come (n_unique null); start[s] = QHULL_START_DEFER where the host has to
 // decide (anything but the plain course of the construction); start_xy (nullable): the vertex's coordinates.
@@ -41,11 +41,15 @@ int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, c
 // all three or none): the slices' strictly convex hulls as unique_hull_dev left them - vertex i of slice s is
 // (hull_x, hull_y)[offsets[s] + hull_idx[offsets[s] + i]] - among whose vertices the kernel then finds the
 // coordinate extremes instead of by a pass over the slice.
+// verts, vcount, vstride (nullable): the kernel also lists the vertices Qhull ends with, in Qhull's order, as (x, y)
+// pairs at verts[s * vstride ...], vcount[s] of them (vcount is left alone where there is no answer; a slice with
+// more than vstride vertices is handed back).
 constexpr int64_t QHULL_START_DEFER = -3;
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                     const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, void *scratch,
                     int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull, const double *hull_x,
-                    const double *hull_y, const int64_t *hull_idx, bool want_index);
+                    const double *hull_y, const int64_t *hull_idx, bool want_index, void *verts = nullptr,
+                    int32_t *vcount = nullptr, int vstride = 0);
 
 // longsort.hip: lexicographic sort of (a, b) pairs inside every slice longer than min_len, and the distinct
 // pairs of the sorted slices (see there)

@@ -596,13 +596,26 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
     const bool on_host = env && env[0] == '1', raw = d_n_pts == nullptr;
     std::vector<int64_t> start((size_t)S, -1);
     std::vector<double> start_xy((size_t)S * 2, 0.0);
-    DevBuf dstart, dxy, dscratch, dtmp;
+    DevBuf dstart, dxy, dscratch, dtmp, dverts, dvcount;
     PCFIT_TRY(dstart.alloc((size_t)S * 8));
     PCFIT_TRY(dxy.alloc((size_t)S * 16));
+    if (max_hull < 0) {                                // (a caller that has not looked at the hulls' sizes)
+        std::vector<int64_t> nh((size_t)S);
+        PCFIT_HIP(hipMemcpyAsync(nh.data(), dnh, (size_t)S * 8, hipMemcpyDeviceToHost, st));
+        PCFIT_HIP(hipStreamSynchronize(st));
+        max_hull = S ? *std::max_element(nh.begin(), nh.end()) : 0;
+    }
+    // The vertices Qhull ends with, per slice, as the replay lists them (the kernel for the slices it answers, the
+    // host replay for the rest): the walks keep those and no others.
+    const int vstride = (int)std::max<int64_t>(3, std::min<int64_t>(max_hull, (int64_t)1 << 20));
+    PCFIT_TRY(dverts.alloc((size_t)S * vstride * 16));
+    PCFIT_TRY(dvcount.alloc((size_t)S * 4));
+    PCFIT_HIP(hipMemsetAsync(dvcount.p, 0xff, (size_t)S * 4, st));       // (-1: no list)
     if (!on_host) {
         PCFIT_TRY(dscratch.alloc((size_t)total * 48));
         PCFIT_TRY(qhull_start_dev(px, py, doff, d_n_pts, dnh, d_hull_start, S, total, dscratch.as<void>(),
-                                  dstart.as<int64_t>(), dxy.as<double>(), st, max_hull, dux, duy, dhi, false));
+                                  dstart.as<int64_t>(), dxy.as<double>(), st, max_hull, dux, duy, dhi, false,
+                                  dverts.as<void>(), dvcount.as<int32_t>(), vstride));
         PCFIT_TRY(dstart.download(start.data(), (size_t)S * 8, st));
         PCFIT_HIP(hipStreamSynchronize(st));
     } else {
@@ -663,25 +676,40 @@ static int apply_qhull_starts_impl(const int64_t *hull_start, const int64_t *d_h
             for (auto &th : pool) th.join();
             if (failed.load()) throw std::bad_alloc();
         }
-        std::vector<int64_t> cstart(which.size(), -1);
+        std::vector<int64_t> cstart(which.size(), -1), cwalk((size_t)coff.back()), cn(which.size(), 0);
         PCFIT_TRY(qhull_start_host(hx, hy, coff.data(), counts.data(), (int64_t)which.size(), 0, nullptr,
-                                   cstart.data(), nullptr, nullptr, nullptr));
+                                   cstart.data(), nullptr, cwalk.data(), cn.data()));
+        std::vector<double> vlist((size_t)2 * vstride);
+        std::vector<int32_t> vn(which.size(), -1);
         for (size_t k = 0; k < which.size(); k++) {
             const int64_t s = which[k];
             start[s] = cstart[k];
             if (cstart[k] >= 0) {
                 start_xy[2 * s] = hx[coff[k] + cstart[k]];
                 start_xy[2 * s + 1] = hy[coff[k] + cstart[k]];
+                if (cn[k] >= 3 && cn[k] <= vstride) {            // the replay's vertices, for the walk to keep
+                    for (int64_t i = 0; i < cn[k]; i++) {
+                        vlist[(size_t)2 * i] = hx[coff[k] + cwalk[(size_t)(coff[k] + i)]];
+                        vlist[(size_t)2 * i + 1] = hy[coff[k] + cwalk[(size_t)(coff[k] + i)]];
+                    }
+                    PCFIT_HIP(hipMemcpy(dverts.as<char>() + (size_t)s * vstride * 16, vlist.data(), (size_t)cn[k] * 16,
+                                        hipMemcpyHostToDevice));
+                    vn[k] = (int32_t)cn[k];
+                }
             }
         }
         // only the handed-back slices' entries changed: they go back one by one
-        for (size_t k = 0; k < which.size(); k++)
+        for (size_t k = 0; k < which.size(); k++) {
             PCFIT_HIP(hipMemcpyAsync(dxy.as<double>() + 2 * which[k], start_xy.data() + 2 * which[k], 16,
                                      hipMemcpyHostToDevice, st));
+            PCFIT_HIP(hipMemcpyAsync(dvcount.as<int32_t>() + which[k], &vn[k], 4, hipMemcpyHostToDevice, st));
+        }
+        PCFIT_HIP(hipStreamSynchronize(st));            // (vn and start_xy: pageable, and vn ends here)
     }
     PCFIT_TRY(dstart.upload(start.data(), (size_t)S * 8, st));
     PCFIT_TRY(dtmp.alloc((size_t)total * 8));
-    PCFIT_TRY(hull_rotate_dev(doff, dnh, dux, duy, dstart.as<int64_t>(), dxy.as<double>(), S, dhi, dtmp.as<int64_t>(), st));
+    PCFIT_TRY(hull_rotate_dev(doff, dnh, dux, duy, dstart.as<int64_t>(), dxy.as<double>(), S, dhi, dtmp.as<int64_t>(), st,
+                              dverts.p, dvcount.as<int32_t>(), vstride));
     PCFIT_HIP(hipStreamSynchronize(st));               // start (pageable) and the buffers end with this call
     return PCFIT_OK;
 }

@@ -389,7 +389,9 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
                                                          const double *__restrict__ hull_x,
                                                          const double *__restrict__ hull_y,
                                                          const int64_t *__restrict__ hull_idx,
-                                                         unsigned long long *__restrict__ why)
+                                                         unsigned long long *__restrict__ why,
+                                                         double2 *__restrict__ verts, int32_t *__restrict__ vcount,
+                                                         int vstride)
 {
     __shared__ Shared<QF, QT> S;
     const int64_t s = blockIdx.x, off = offsets[s];
@@ -1062,11 +1064,23 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
             // the hull the other kernel found by an exact predicate has these vertices and, where coordinates were
             // rounded, some at the slightest of turns that Qhull does not keep (the turn of the walk takes them out);
             // fewer there than here would mean that something was missed
-            if (nw == k && count <= n_hull[s]) {
+            if (nw == k && count <= n_hull[s] && (!verts || count <= vstride)) {
                 const int h = walk[best_first];
                 S.sx[0] = S.top[h] ? S.vx0[h] : S.vx1[h];
                 S.sy[0] = S.top[h] ? S.vy0[h] : S.vy1[h];
                 answered = true;
+                // the vertices Qhull ends with, in its order (one per facet or run of facets in line): which of the
+                // exact hull's vertices they are is for the caller to look up - the exact hull keeps a vertex at
+                // the slightest turn, Qhull never makes one of a point that no facet ever saw outside
+                if (verts) {
+                    int n_out = 0;
+                    for (int t = 0, i = best_first; t < nw; t++, i = (i + 1) % nw)
+                        if (!joined[i]) {
+                            const int f = walk[i];
+                            verts[(int64_t)s * vstride + n_out++] = make_double2(S.top[f] ? S.vx0[f] : S.vx1[f], S.top[f] ? S.vy0[f] : S.vy1[f]);
+                        }
+                    vcount[s] = n_out;
+                }
             } else
                 S.reason = 12;
         } else if (S.state == 0)
@@ -1106,7 +1120,8 @@ __global__ __launch_bounds__(QT, WG) void qhull_order_kernel(const double *__res
 int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, const int64_t *n_unique,
                     const int64_t *n_hull, const int64_t *select, int64_t n_slices, int64_t total, void *scratch,
                     int64_t *start, double *start_xy, hipStream_t st, int64_t max_hull, const double *hull_x,
-                    const double *hull_y, const int64_t *hull_idx, bool want_index)
+                    const double *hull_y, const int64_t *hull_idx, bool want_index, void *verts, int32_t *vcount,
+                    int vstride)
 {
     if (n_slices <= 0) return PCFIT_OK;
     // The form with the fewest facet slots that holds the largest hull of the batch and two dozen facets more: the
@@ -1149,7 +1164,8 @@ int qhull_start_dev(const double *ux, const double *uy, const int64_t *offsets, 
 #define PCFIT_QHULL_LAUNCH(QF, WG, QT)                                                                              \
     qhull_order_kernel<QF, WG, QT><<<grid, dim3(QT), 0, st>>>(ux, uy, offsets, n_unique, n_hull, select, pairs,     \
                                                               pairs + total, start, start_xy, want_index ? 1 : 0, \
-                                                              hull_x, hull_y, hull_idx, why)
+                                                              hull_x, hull_y, hull_idx, why,                    \
+                                                              reinterpret_cast<double2 *>(verts), vcount, vstride)
     switch (form) {
     case 96: PCFIT_QHULL_LAUNCH(96, 5, 256); break;
     case 97: PCFIT_QHULL_LAUNCH(96, 10, 64); break;

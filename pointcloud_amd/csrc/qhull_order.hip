@@ -516,82 +516,63 @@ void Replay::walk(int64_t *out, int64_t cap, int64_t *first)
 }
 
 // A device array of walks turned to start at the vertex with the given coordinates (no change where found[s] < 0
-// or no vertex has them), and brought to Qhull's vertex set: the walks come from an exact predicate and keep a
-// vertex at the slightest turn, Qhull merges two edges whose far end lies within its roundoff of the other's
-// line (coordinates rounded to a few decimals make such vertices), so a vertex goes when the centrum of the edge
-// before or after it lies within the centrum radius of the other's line - the rule the replay applies to its
-// own facets.  n_hull[s] becomes the number of vertices left.
+// or no vertex has them), and brought to Qhull's vertex set.  The walks come from an exact predicate and keep a
+// vertex at the slightest turn; Qhull's result lacks some of them - it merges two edges whose far end lies within its
+// roundoff of the other's line (coordinates rounded to a few decimals make such vertices), and it never makes a
+// vertex of a point that no facet ever saw outside by its threshold (a point 2.7 roundoff units beyond the chord of
+// its neighbours, 7e6 from the origin).  Which vertices Qhull ends with depends on the course of its construction,
+// so the replay says it: verts holds vcount[s] coordinate pairs per slice (vstride apart), and the walk keeps the
+// vertices found among them, in its own order from the start vertex on.  n_hull[s] becomes their number.  A slice
+// whose list names a point that is no vertex of the walk keeps its walk whole (and its turn).
 __global__ __launch_bounds__(256) void hull_rotate_kernel(const int64_t *__restrict__ offsets, int64_t *__restrict__ n_hull,
                                                           const double *__restrict__ ux, const double *__restrict__ uy,
                                                           const int64_t *__restrict__ found,
                                                           const double *__restrict__ start_xy,
-                                                          int64_t *__restrict__ hull_idx, int64_t *__restrict__ tmp)
+                                                          int64_t *__restrict__ hull_idx, int64_t *__restrict__ tmp,
+                                                          const double2 *__restrict__ verts,
+                                                          const int32_t *__restrict__ vcount, int vstride)
 {
-    __shared__ int found_at, any_joined;
-    __shared__ unsigned long long max_ax, max_ay;
+    __shared__ int found_at, n_named;
     const int64_t s = blockIdx.x, off = offsets[s], h = n_hull[s];
     if (found[s] < 0 || h <= 0)
         return;
     const double sx = start_xy[2 * s], sy = start_xy[2 * s + 1];
     if (threadIdx.x == 0) {
         found_at = 0x7fffffff;
-        any_joined = 0;
-        max_ax = max_ay = 0ull;
+        n_named = 0;
     }
     __syncthreads();
+    const int nv = verts && vcount ? vcount[s] : -1;
+    const double2 *list = verts ? verts + s * (int64_t)vstride : nullptr;
+    // tmp: the walk's vertices, the bit above the index set where Qhull's list names the vertex
     for (int64_t i = threadIdx.x; i < h; i += 256) {
         const int64_t v = hull_idx[off + i];
-        tmp[off + i] = v;
-        if (ux[off + v] == sx && uy[off + v] == sy)
+        const double px = ux[off + v], py = uy[off + v];
+        bool named = nv < 3;
+        for (int k = 0; k < nv && !named; k++)
+            named = list[k].x == px && list[k].y == py;
+        tmp[off + i] = v | (named ? (int64_t)1 << 62 : 0);
+        if (named && nv >= 3) atomicAdd(&n_named, 1);
+        if (px == sx && py == sy)
             atomicMin(&found_at, (int)i);
-        // (the largest coordinates of a slice are those of hull vertices; non-negative doubles order like their bits)
-        atomicMax(&max_ax, (unsigned long long)__double_as_longlong(fabs(ux[off + v])));
-        atomicMax(&max_ay, (unsigned long long)__double_as_longlong(fabs(uy[off + v])));
     }
     __syncthreads();
     const int64_t p0 = found_at == 0x7fffffff ? 0 : found_at;
-    const double ax = __longlong_as_double((long long)max_ax), ay = __longlong_as_double((long long)max_ay);
-    const double maxabs = fmax(ax, ay);
-    const double distround = 2.220446049250313e-16 * (2 * fmin(sqrt(2.0) * maxabs, ax + ay) * 1.01 + maxabs);
-    auto vertex = [&](int64_t i) { return tmp[off + (i + p0 + h) % h]; };          // the walk from the start vertex
-    // does vertex i of that walk go?  Qhull's test of the edges before and after it: the centrum of one (the mean of
-    // its ends, brought onto its own line) within the centrum radius - twice the roundoff - of the other's line
-    auto joined = [&](int64_t i) {
-        const int64_t a = vertex(i - 1), b = vertex(i), c = vertex(i + 1);
-        const double px[3] = {ux[off + a], ux[off + b], ux[off + c]}, py[3] = {uy[off + a], uy[off + b], uy[off + c]};
-        double n0[2], n1[2], o[2];
-        for (int e = 0; e < 2; e++) {
-            const double nx = py[e + 1] - py[e], ny = px[e] - px[e + 1], norm = sqrt(nx * nx + ny * ny);
-            n0[e] = nx / norm;
-            n1[e] = ny / norm;
-            o[e] = -(px[e] * n0[e] + py[e] * n1[e]);
-        }
-        bool in_line = false;
-        for (int e = 0; e < 2; e++) {
-            double cx = (px[e] + px[e + 1]) / 2, cy = (py[e] + py[e + 1]) / 2;
-            const double own = o[e] + cx * n0[e] + cy * n1[e];
-            cx -= own * n0[e];
-            cy -= own * n1[e];
-            const double d = o[1 - e] + cx * n0[1 - e] + cy * n1[1 - e];
-            in_line = in_line || fabs(d) <= 2 * distround;
-        }
-        return in_line;
-    };
-    for (int64_t i = threadIdx.x; i < h; i += 256) {
-        hull_idx[off + i] = vertex(i);
-        if (i > 0 && h > 3 && joined(i)) any_joined = 1;
+    const bool reduce = nv >= 3 && n_named == nv && nv < h;           // (every listed point is a vertex of the walk)
+    const int64_t mask = ((int64_t)1 << 62) - 1;
+    if (!reduce) {
+        for (int64_t i = threadIdx.x; i < h; i += 256)
+            hull_idx[off + i] = tmp[off + (i + p0) % h] & mask;
+        return;
     }
-    __syncthreads();
-    if (!any_joined || threadIdx.x != 0)
+    if (threadIdx.x != 0)
         return;
-    // rare: one thread closes the gaps, in order (the start vertex stays whatever its angle)
-    int64_t n_joined = 0;
-    for (int64_t i = 1; i < h; i++) n_joined += joined(i);
-    if (h - n_joined < 3)
-        return;
-    int64_t kept = 1;
-    for (int64_t i = 1; i < h; i++)
-        if (!joined(i)) hull_idx[off + kept++] = vertex(i);
+    // one thread closes the gaps, in order
+    int64_t kept = 0;
+    for (int64_t i = 0; i < h; i++) {
+        const int64_t t = tmp[off + (i + p0) % h];
+        if (t >> 62) hull_idx[off + kept++] = t & mask;
+    }
     n_hull[s] = kept;
 }
 
@@ -647,11 +628,12 @@ int qhull_start_host(const double *ux, const double *uy, const int64_t *offsets,
 
 int hull_rotate_dev(const int64_t *offsets, int64_t *n_hull, const double *ux, const double *uy,
                     const int64_t *found, const double *start_xy, int64_t n_slices, int64_t *hull_idx, int64_t *tmp,
-                    hipStream_t st)
+                    hipStream_t st, const void *verts, const int32_t *vcount, int vstride)
 {
     if (n_slices <= 0) return PCFIT_OK;
     hull_rotate_kernel<<<dim3((unsigned)n_slices), dim3(256), 0, st>>>(offsets, n_hull, ux, uy, found, start_xy, hull_idx,
-                                                                       tmp);
+                                                                       tmp, static_cast<const double2 *>(verts), vcount,
+                                                                       vstride);
     PCFIT_LAUNCH_CHECK();
     return PCFIT_OK;
 }
