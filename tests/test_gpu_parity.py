@@ -687,6 +687,30 @@ def test_replay_over_slices_with_many_copies_of_every_point():
             assert np.array_equal(raw[k], srt[k]), (rep, k)
 
 
+def test_the_walk_keeps_the_vertices_qhull_ends_with_and_no_others():
+    """tests/golden/qhull_far_vertex.npz: the exact hull of this slice has 81 vertices, scipy lists 80 (point 875 is
+    2.7 roundoff units beyond its neighbours' chord: never outside of a facet by Qhull's threshold).  The library's
+    walk in Qhull's order is scipy's list, with the kernel deciding and with the host replay deciding, sorted and as
+    the slice comes with copies."""
+    g = load_golden("qhull_far_vertex")
+    xy, want = g["xy"], g["vertices"]
+    x, y = np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1])
+    plain = F.unique_hull_batch(x, y, None)
+    assert int(plain["n_hull"][0]) == len(want) + 1
+    try:
+        for on_host in ("0", "1"):
+            os.environ["PCFIT_QHULL_ON_HOST"] = on_host
+            h = F.unique_hull_batch(x, y, None, hull_start="qhull")
+            assert np.array_equal(h["hull_idx"][:int(h["n_hull"][0])], want), on_host
+            gen = np.random.default_rng(5)
+            raw = np.repeat(xy, 2, axis=0)[gen.permutation(2 * len(xy))]
+            hy = F.hybrid_batch(np.ascontiguousarray(raw[:, 0]), np.ascontiguousarray(raw[:, 1]), None, max_trials=20,
+                                want_profile=False, want_unique=False, order="qhull")
+            assert np.array_equal(np.stack([hy["cand_x"], hy["cand_y"]], 1), xy[want]), on_host
+    finally:
+        os.environ.pop("PCFIT_QHULL_ON_HOST", None)
+
+
 def test_analyzer_in_qhulls_order_equals_the_reference_run_on_every_slice():
     """The analyzer as it comes (Config.hull_order = "qhull"): its candidates are the reference's
     `xy[hull.vertices]` in the reference's order, so every slice - the three whose hull holds outliers included -

@@ -94,3 +94,16 @@ def test_slices_without_a_hull_and_ragged_batches():
     # n_unique shorter than the slice's room: only the first n_unique points count
     r2 = F.qhull_order_batch(x, y, off, n_unique=np.array([2, 0, 3, 3, 2], np.int64))
     assert r2["start"][4] == -1
+
+
+def test_a_vertex_of_the_exact_hull_that_qhull_never_makes():
+    """1500 points 7.3e6 from the origin (tests/golden/qhull_far_vertex.npz: a slice the randomised device sweep drew,
+    with scipy's list): point 875 lies 2.7 roundoff units beyond the chord of its neighbours - a vertex of the exact
+    hull, none of Qhull's, which asks four units of an outside point.  The host replay and the Python restatement list
+    scipy's 80 vertices."""
+    g = load_golden("qhull_far_vertex")
+    xy, want = g["xy"], g["vertices"]
+    host = F.qhull_order_batch(np.ascontiguousarray(xy[:, 0]), np.ascontiguousarray(xy[:, 1]), None)
+    assert np.array_equal(host["walk"][:int(host["n_walk"][0])], want)
+    verts, _ = Q.vertices(xy)
+    assert np.array_equal(np.asarray(verts), want)
