@@ -81,14 +81,14 @@ def make_slice(g, n):
 def few_points_tol(xy, radius):
     """What three or four points leave to rounding, against the circle's size: 1e-7 when they are almost in line (a
     circle twenty times their spread: one coordinate moved by a unit in the last place moves it by 4e-9), and 1e-9
-    times a ten-thousandth of (spread / least distance between two of them)^2 when two of them nearly coincide - the
-    normal equations square that ratio (points 0.03 apart and 28 from the third: two kernels 1.1e-9 apart)."""
+    times a thousandth of (spread / least distance between two of them)^2 when two of them nearly coincide - the
+    normal equations square that ratio (points 0.03 apart and 28 from the third: two kernels 1.1e-9 apart; 6.5e-8 apart and 2.4e-5 from the third: 3.0e-8)."""
     spread = float(np.ptp(xy[:, 0]) + np.ptp(xy[:, 1]))
     if abs(radius) > 20.0 * spread:
         return 1e-7
     u = np.unique(xy, axis=0)
     d = min(float(np.hypot(*(u[i] - u[j]))) for i in range(len(u)) for j in range(i))
-    return 1e-9 * max(1.0, 1e-4 * (spread / d) ** 2) if d > 0 else 1e-7
+    return 1e-9 * max(1.0, 1e-3 * (spread / d) ** 2) if d > 0 else 1e-7
 
 
 def in_one_line(xy):
@@ -161,7 +161,7 @@ def one_round(seed):
                 note(seed, int(s), "fused residual statistics", tag)
             if max_iter == 0 and not np.array_equal(fu["fit"][s], fu["kasa"][s]):
                 note(seed, int(s), "fused fit without LM is not its Kasa circle", tag)
-            if kinds[s] in ("ring", "dups", "tiny", "grid") and sizes[s] >= 3:
+            if kinds[s] in ("ring", "dups", "tiny", "grid") and sizes[s] >= 3 and not (sizes[s] <= 16 and in_one_line(sets[s])):
                 want = lm[s] if max_iter else kasa[s]
                 err = float(np.max(np.abs(fu["fit"][s] - want)) / np.abs(want).max())     # against the circle's size
                 if not err <= (few_points_tol(sets[s], want[2]) if sizes[s] <= 4 else 1e-9):
