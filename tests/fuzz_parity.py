@@ -193,6 +193,10 @@ def one_round(seed):
             # 1e-15 perturbation of the input moves the CPU result by 1e-6 - conditioning, not arithmetic)
             if kinds[s] == "arc" and abs(want[2]) > 100.0:
                 tol = 1e-4
+            # (the same for a handful of points almost in line, whatever their kind: a loop that runs off to a circle a
+            # hundred times their spread - radius 28 046 after 94 accepted steps, still growing - has no limit to agree on)
+            if n <= 16 and abs(want[2]) > 100.0 * float(np.ptp(xy[:, 0]) + np.ptp(xy[:, 1])):
+                tol = 1e-4
             # (errors against the circle's size where a centre coordinate may be arbitrarily close to zero)
             scale = np.abs(want).max() if kinds[s] in ("far", "tiny") else None
             err = float(np.max(np.abs(lm[s] - want)) / scale) if scale else rel(lm[s], want)
